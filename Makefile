@@ -1,0 +1,42 @@
+# Top-level build: host pipeline (g++), HIP module for gfx950 (hipcc), CPU oracle (gcc).
+# No cmake needed; __graft_entry__.build() drives this same file.
+ROOT     := $(abspath $(dir $(lastword $(MAKEFILE_LIST))))
+PKG      := $(ROOT)/jaderaytracerendering_amd
+LIBDIR   := $(PKG)/lib
+HIPCC    ?= /opt/rocm/bin/hipcc
+CXX      ?= g++
+# -ffp-contract=off everywhere: include/jade_fpmath.h pins the evaluation order.
+FPFLAGS  := -ffp-contract=off -fno-fast-math
+CXXFLAGS := -O2 -g -std=c++17 -fPIC -mfma $(FPFLAGS) -Wall -Wextra -Wno-unused-parameter -I$(ROOT)/include -I$(PKG)/host
+HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=gfx950 $(FPFLAGS) -fhip-fp32-correctly-rounded-divide-sqrt \
+            -fno-gpu-flush-denormals-to-zero -mfma -Wall -Wno-unused-parameter -I$(ROOT)/include -I$(PKG)/csrc
+
+HOST_SRC := $(PKG)/host/scene_build.cpp $(PKG)/host/scene_io.cpp $(PKG)/host/host_capi.cpp
+HOST_HDR := $(PKG)/host/jade_host.hpp $(ROOT)/include/jade_host_c.h $(ROOT)/include/jade_rt.h $(ROOT)/include/jade_fpmath.h
+HIP_SRC  := $(wildcard $(PKG)/csrc/*.hip)
+HIP_HDR  := $(wildcard $(PKG)/csrc/*.h) $(ROOT)/include/jade_rt.h $(ROOT)/include/jade_fpmath.h
+
+all: host hip oracle cli
+
+host: $(LIBDIR)/libjade_host.so
+hip: $(LIBDIR)/libjade_hip.so
+cli: $(LIBDIR)/jade_render
+oracle:
+	$(MAKE) -C $(ROOT)/oracle
+
+$(LIBDIR)/libjade_host.so: $(HOST_SRC) $(HOST_HDR)
+	@mkdir -p $(LIBDIR)
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC)
+
+$(LIBDIR)/libjade_hip.so: $(HIP_SRC) $(HIP_HDR)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC)
+
+$(LIBDIR)/jade_render: $(PKG)/host/jade_render_cli.cpp $(LIBDIR)/libjade_host.so $(HOST_HDR)
+	$(CXX) $(CXXFLAGS) -o $@ $(PKG)/host/jade_render_cli.cpp -L$(LIBDIR) -ljade_host -ldl -Wl,-rpath,'$$ORIGIN'
+
+clean:
+	rm -rf $(LIBDIR)
+	$(MAKE) -C $(ROOT)/oracle clean
+
+.PHONY: all host hip oracle cli clean

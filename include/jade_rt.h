@@ -1,0 +1,188 @@
+/*
+ * jade_rt.h — the C ABI of the jade path-tracing hot path.
+ *
+ * This is the seam SURVEY.md §8(b) identifies in the reference: everything
+ * between "the flat host arrays are ready" (PathTrace.cu:1570-1612) and "the
+ * BGR bytes are back on the host" (PathTrace.cu:1739).  The reference has no
+ * plugin/FFI API; its implicit interface is the argument list of the
+ * `render_pixel` kernel plus six __constant__ symbols
+ * (PathTrace.cu:643-648, 1418, 1704-1710, 1731).  The entry points below carry
+ * exactly that information: plain pointers and sizes, `int` status codes, no
+ * exceptions, no exit() across the boundary (the reference prints CUDA errors
+ * and carries on, PathTrace.cu:1476-1482; here every failure is a status plus
+ * a thread-local message).
+ *
+ * Two shared libraries implement this same header:
+ *   libjade_hip.so     the product: hand-written HIP for gfx950 (MI355X)
+ *   libjade_oracle.so  test infrastructure: a single-purpose CPU restatement
+ *                      of PathTrace.cu:669-1474 (oracle/), never shipped and
+ *                      never called by the product path
+ *
+ * The array element types mirror the reference's device structs byte for
+ * byte so that a maintainer can pass `&triangles_encoded[0]` and
+ * `&nodes_encoded[0]` straight through.
+ */
+#ifndef JADE_RT_H
+#define JADE_RT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JADE_ABI_VERSION 1
+
+/* status codes */
+#define JADE_OK 0
+#define JADE_ERR_INVALID 1     /* bad argument / inconsistent scene arrays */
+#define JADE_ERR_DEVICE 2      /* HIP runtime failure, no device */
+#define JADE_ERR_NOMEM 3       /* host or device allocation failed */
+#define JADE_ERR_UNSUPPORTED 4 /* e.g. BVH deeper than the traversal stack */
+
+/* material modes (PathTrace.cu:41-45; DIR_REFRACT: PathTrace.cpp:34) */
+#define JADE_DIFFUSE 0
+#define JADE_MIRROR 1
+#define JADE_NO_REFRACT 0
+#define JADE_SUB_SURFACE 1
+#define JADE_DIR_REFRACT 2
+
+/* Fixed constants of the integrator (PathTrace.cu:32-39); not parameters. */
+#define JADE_TILE_SIZE 16
+#define JADE_STACK_CAPACITY 128     /* bounce pushes per sample */
+#define JADE_BVH_STACK_CAPACITY 128 /* traversal stack entries */
+#define JADE_MAX_FULL_REFLEX_TIME 32
+
+/* == Triangle_cu, PathTrace.cu:327-338 (112 bytes). */
+typedef struct jade_triangle {
+  int32_t obj_idx;
+  float p1[3], p2[3], p3[3];
+  float norm[3];
+  float emissive[3];
+  float brdf[3];
+  int32_t reflex_mode;
+  int32_t refract_mode;
+  float refract_rate[3];
+  float refract_albedo[3];
+  float refract_index;
+} jade_triangle;
+
+/* == BVHNode_cu, PathTrace.cu:341-345 (40 bytes).  nodes[0] is a dummy, the
+ * root is nodes[1], a child index of 0 means "none", n > 0 marks a leaf
+ * holding triangles [index, index + n - 1] (PathTrace.cu:525-529, 804, 825,
+ * 1557-1565). */
+typedef struct jade_bvh_node {
+  int32_t left, right;
+  int32_t n, index;
+  float aa[3], bb[3];
+} jade_bvh_node;
+
+/* == Obj_seg, PathTrace.cu:348-351: inclusive range in ORIGINAL (pre-BVH)
+ * triangle order. */
+typedef struct jade_obj_seg {
+  int32_t begin_idx;
+  int32_t end_idx;
+} jade_obj_seg;
+
+/* Everything `render_pixel` reads (PathTrace.cu:1418 + 639-648).  All
+ * pointers are host pointers; jade_scene_create copies, the caller keeps
+ * ownership. */
+typedef struct jade_scene_desc {
+  uint32_t abi_version;           /* JADE_ABI_VERSION */
+  int32_t n_triangles;            /* nTriangles_dv */
+  const jade_triangle* triangles; /* triangles_cu, BVH (sorted) order */
+  int32_t n_nodes;                /* nNodes_dv, including the dummy node 0 */
+  const jade_bvh_node* nodes;     /* node_cu */
+  int32_t n_emit;                 /* nEmitTriangles_dv */
+  const int32_t* emit_indices;    /* emitTrianglesIndices_cu (sorted order) */
+  const int32_t* index_mapping;   /* triangle_index_mapping_cu: original -> sorted, [n_triangles] */
+  const float* prefix_area;       /* prefix_size_sum_cu: per-object running area, original order */
+  int32_t n_objects;
+  const jade_obj_seg* obj_segs;   /* obj_segs_cu */
+  int32_t env_width, env_height;  /* HDR environment, equirectangular */
+  const float* env_rgb;           /* hdrRes.cols: interleaved RGB, row 0 = top (v = 0) */
+} jade_scene_desc;
+
+typedef struct jade_render_params {
+  int32_t width, height; /* RENDER_WIDTH / RENDER_HEIGHT, run-time here */
+  int32_t spp;           /* samples per pixel rendered by this call */
+  uint32_t frame;        /* RNG frame counter (seed term), normally 0 */
+  float eye[3];          /* eye_dv */
+  float camera[16];      /* camera_transform_dv, [col][row] memory order */
+  /* image partition: this call renders the 16x16 tiles whose row-major id
+   * satisfies id % tile_nranks == tile_rank (single GPU: 0 of 1) */
+  int32_t tile_rank, tile_nranks;
+  int32_t device_id;     /* HIP device ordinal (ignored by the oracle) */
+  int32_t threads;       /* oracle: worker threads (0 = all cores); HIP: ignored */
+} jade_render_params;
+
+/* Exact integer work counters; the oracle's and the HIP module's must be
+ * equal for the same inputs.  One "ray" is one hitBVH query
+ * (PathTrace.cu:795). */
+typedef struct jade_stats {
+  uint64_t rays_primary;   /* PathTrace.cu:1440 */
+  uint64_t rays_secondary; /* every other hitBVH call site */
+  uint64_t nodes_visited;  /* V: root + both children of each internal node popped */
+  uint64_t tris_tested;    /* T: hitTriangle calls (source triangle excluded) */
+  uint64_t shaded_hits;    /* H: pathTracing loop iterations (vertices shaded) */
+  uint64_t samples;        /* pixels * spp rendered by this call */
+  double kernel_ms;        /* device (or CPU wall) time inside the integrator */
+} jade_stats;
+
+typedef struct jade_scene jade_scene; /* opaque */
+
+int jade_abi_version(void);
+const char* jade_backend_name(void);  /* "hip-gfx950" | "oracle-cpu" */
+const char* jade_last_error(void);    /* thread-local text of the last failure */
+int jade_device_count(int* n);
+
+/* Validates the arrays (index ranges, BVH depth <= JADE_BVH_STACK_CAPACITY - 1)
+ * and builds the backend's private copy.  Replaces PathTrace.cu:1618-1698. */
+int jade_scene_create(const jade_scene_desc* desc, int device_id, jade_scene** out);
+void jade_scene_destroy(jade_scene* scene);
+
+/* Renders the caller's tiles.  Replaces PathTrace.cu:1704-1739 (constant
+ * upload, RNG init, kernel launch, sync, D2H copy).
+ *   out_rgb  nullable, width*height*3 floats: linear mean radiance before tone
+ *            mapping (PathTrace.cu:1457), RGB, pixel (x, y) at 3*(y*width+x),
+ *            y grows upward as in the reference (PathTrace.cu:1470).
+ *   out_bgr8 nullable, width*height*3 bytes: ACES + gamma + BGR pack exactly
+ *            as PathTrace.cu:1461-1473 (what save_image() writes).
+ * Pixels of tiles this rank does not own are left untouched.
+ * Synchronous; one render in flight per scene. */
+int jade_render(jade_scene* scene, const jade_render_params* params, float* out_rgb,
+                uint8_t* out_bgr8, jade_stats* stats);
+
+/* Progressive form: the per-pixel RNG state and radiance sums persist on the
+ * backend between calls, so N calls of spp samples equal one call of N*spp
+ * (the reference's own running-mean preview, fshader_preview.fsh:402-403, is
+ * the model).  begin() resets the accumulation; step() adds `spp` samples to
+ * every owned pixel and leaves the results on the backend; resolve() writes
+ * the mean so far.  jade_render == begin + step + resolve. */
+int jade_render_begin(jade_scene* scene, const jade_render_params* params);
+int jade_render_step(jade_scene* scene, int32_t spp, jade_stats* stats_accum);
+int jade_render_resolve(jade_scene* scene, float* out_rgb, uint8_t* out_bgr8);
+
+/* Device-resident resolve for multi-GPU gathers (HIP backend only; the oracle
+ * returns JADE_ERR_UNSUPPORTED).  Writes this rank's tiles compactly into
+ * device memory: tile t (t-th owned tile in increasing id order) occupies
+ * floats [t*768, (t+1)*768) as 16x16 RGB rows.  `dev_tiles` must hold
+ * jade_owned_tile_count()*768 floats.  `stream` is a hipStream_t (0 = null
+ * stream).  Out-of-image pixels of edge tiles are written as 0. */
+int jade_render_resolve_tiles_device(jade_scene* scene, float* dev_tiles, void* stream);
+int jade_owned_tile_count(int32_t width, int32_t height, int32_t tile_rank, int32_t tile_nranks);
+
+/* Single-query entry point used by the parity tests: traces `n` rays through
+ * the scene's BVH with hitBVH semantics (PathTrace.cu:795-859).
+ *   origins/dirs: n*3 floats; skip: n source-triangle indices (-1 = none)
+ *   hit_index: n (-1 on miss); hit_dist: n; hit_point: n*3
+ *   stats: nodes_visited / tris_tested / rays_secondary are accumulated */
+int jade_trace_rays(jade_scene* scene, int32_t n, const float* origins, const float* dirs,
+                    const int32_t* skip, int32_t* hit_index, float* hit_dist, float* hit_point,
+                    jade_stats* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JADE_RT_H */

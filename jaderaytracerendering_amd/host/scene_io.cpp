@@ -1,0 +1,373 @@
+// scene_io.cpp — environment maps, camera, render_args.txt, image writers and
+// the built-in benchmark configurations.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+#include "jade_host.hpp"
+
+namespace jadehost {
+
+// ------------------------------------------------------------ environment ----
+
+EnvMap make_env_constant(float r, float g, float b) {
+  EnvMap e;
+  e.width = 2;
+  e.height = 2;
+  for (int i = 0; i < 4; ++i) { e.rgb.push_back(r); e.rgb.push_back(g); e.rgb.push_back(b); }
+  return e;
+}
+
+EnvMap make_env_sky(int width, int height) {
+  // Procedural equirectangular sky (background.hdr is git-ignored in the
+  // reference): horizon-to-zenith gradient, dim ground, one sun lobe.  The
+  // texel->direction map inverts SampleSphericalMap (PathTrace.cu:686-694).
+  EnvMap e;
+  e.width = width;
+  e.height = height;
+  e.rgb.resize((size_t)3 * width * height);
+  const jvec3 sun = jv_normalize(jv(-0.35f, 0.75f, 0.55f));
+  for (int j = 0; j < height; ++j) {
+    float v = ((float)j + 0.5f) / (float)height;
+    float elev = (0.5f - v) * 3.14159265f;  // asin(y)
+    float sy, cy;
+    jade_sincosf(elev, &sy, &cy);
+    for (int i = 0; i < width; ++i) {
+      float u = ((float)i + 0.5f) / (float)width;
+      float az = (u - 0.5f) * 6.2831853f;  // atan2(z, x)
+      float sa, ca;
+      jade_sincosf(az, &sa, &ca);
+      jvec3 d = jv(cy * ca, sy, cy * sa);
+      float t = d.y > 0 ? d.y : 0.0f;
+      jvec3 c;
+      if (d.y >= 0) {
+        c = jv(0.55f - 0.35f * t, 0.70f - 0.25f * t, 0.95f - 0.05f * t);
+        c = jv_scale(c, 0.9f + 0.6f * (1.0f - t));
+      } else {
+        float g = 0.18f + 0.10f * (-d.y);
+        c = jv(g * 1.05f, g, g * 0.9f);
+      }
+      float cs = jv_dot(d, sun);
+      if (cs > 0) {
+        float lobe = jade_powf(cs, 96.0f) * 9.0f + jade_powf(cs, 8.0f) * 0.6f;
+        c = jv_add(c, jv(lobe, lobe * 0.95f, lobe * 0.85f));
+      }
+      float* px = &e.rgb[3 * ((size_t)j * width + i)];
+      px[0] = c.x > 10 ? 10 : c.x;
+      px[1] = c.y > 10 ? 10 : c.y;
+      px[2] = c.z > 10 ? 10 : c.z;
+    }
+  }
+  return e;
+}
+
+// Radiance RGBE (.hdr) reader standing in for the un-vendored lib/hdrloader
+// (PathTrace.cu:1648-1649): flat and new-style RLE scanlines, -Y h +X w.
+bool load_hdr(const std::string& path, EnvMap& out, std::string& err) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) { err = "File " + path + " open failed."; return false; }
+  char line[512];
+  bool ok = false;
+  int w = 0, h = 0;
+  if (!fgets(line, sizeof line, f) || (strncmp(line, "#?RADIANCE", 10) != 0 && strncmp(line, "#?RGBE", 6) != 0)) {
+    err = path + ": not a Radiance HDR file";
+    fclose(f);
+    return false;
+  }
+  while (fgets(line, sizeof line, f)) {
+    if (line[0] == '\n' || line[0] == '\r') {
+      if (fgets(line, sizeof line, f) && sscanf(line, "-Y %d +X %d", &h, &w) == 2) ok = true;
+      break;
+    }
+  }
+  if (!ok || w <= 0 || h <= 0 || (int64_t)w * h > (1 << 28)) {
+    err = path + ": unsupported HDR header";
+    fclose(f);
+    return false;
+  }
+  out.width = w;
+  out.height = h;
+  out.rgb.assign((size_t)3 * w * h, 0.0f);
+  std::vector<unsigned char> scan((size_t)4 * w);
+  for (int y = 0; y < h; ++y) {
+    unsigned char hd[4];
+    if (fread(hd, 1, 4, f) != 4) { err = path + ": truncated"; fclose(f); return false; }
+    if (w >= 8 && w < 32768 && hd[0] == 2 && hd[1] == 2 && ((hd[2] << 8) | hd[3]) == w) {
+      for (int ch = 0; ch < 4; ++ch) {
+        int x = 0;
+        while (x < w) {
+          int c = fgetc(f);
+          if (c == EOF) { err = path + ": truncated"; fclose(f); return false; }
+          if (c > 128) {
+            int n = c - 128, v = fgetc(f);
+            if (v == EOF || x + n > w) { err = path + ": bad RLE"; fclose(f); return false; }
+            while (n--) scan[4 * (size_t)(x++) + ch] = (unsigned char)v;
+          } else {
+            int n = c;
+            if (n == 0 || x + n > w) { err = path + ": bad RLE"; fclose(f); return false; }
+            while (n--) {
+              int v = fgetc(f);
+              if (v == EOF) { err = path + ": truncated"; fclose(f); return false; }
+              scan[4 * (size_t)(x++) + ch] = (unsigned char)v;
+            }
+          }
+        }
+      }
+    } else {
+      memcpy(scan.data(), hd, 4);
+      if (w > 1 && fread(scan.data() + 4, 4, (size_t)w - 1, f) != (size_t)w - 1) { err = path + ": truncated"; fclose(f); return false; }
+    }
+    for (int x = 0; x < w; ++x) {
+      const unsigned char* p = &scan[4 * (size_t)x];
+      float* o = &out.rgb[3 * ((size_t)y * w + x)];
+      if (p[3] == 0) { o[0] = o[1] = o[2] = 0; continue; }
+      float sc = std::ldexp(1.0f, (int)p[3] - (128 + 8));
+      o[0] = p[0] * sc; o[1] = p[1] * sc; o[2] = p[2] * sc;
+    }
+  }
+  fclose(f);
+  return true;
+}
+
+// ----------------------------------------------------------------- camera ----
+
+void camera_orbit(float r, float up_deg, float rot_deg, const float center[3], float eye_out[3], float cam_out[16]) {
+  // eye = r * (-sin(rot)cos(up), sin(up), cos(rot)cos(up))   (PathTrace.cpp:684-685)
+  float su, cu, sr, cr;
+  jade_sincosf(up_deg * 0.017453292519943295f, &su, &cu);
+  jade_sincosf(rot_deg * 0.017453292519943295f, &sr, &cr);
+  jvec3 eye = jv(-sr * cu * r, su * r, cr * cu * r);
+  jvec3 ctr = jv(center[0], center[1], center[2]);
+  // inverse(lookAt(eye, center, up)): columns = right, up', -forward, eye
+  jvec3 f = jv_normalize(jv_sub(ctr, eye));
+  jvec3 s = jv_normalize(jv_cross(f, jv(0, 1, 0)));
+  jvec3 u = jv_cross(s, f);
+  const float m[16] = {s.x, s.y, s.z, 0, u.x, u.y, u.z, 0, -f.x, -f.y, -f.z, 0, eye.x, eye.y, eye.z, 1};
+  memcpy(cam_out, m, sizeof m);
+  eye_out[0] = eye.x; eye_out[1] = eye.y; eye_out[2] = eye.z;
+}
+
+// -------------------------------------------------------- render_args.txt ----
+
+bool read_render_args(const std::string& path, RenderArgs& out, std::string& err) {
+  std::ifstream fin(path);
+  if (!fin.is_open()) { err = "File " + path + " open failed."; return false; }
+  fin >> out.eye[0] >> out.eye[1] >> out.eye[2];
+  for (int i = 0; i < 16; ++i) fin >> out.camera[i];
+  int n = 0;
+  fin >> n;
+  if (!fin || n < 0 || n > 100000) { err = path + ": malformed header"; return false; }
+  out.objects.resize(n);
+  for (RenderArgsObject& o : out.objects) {
+    fin >> o.file;
+    for (int i = 0; i < 16; ++i) fin >> o.trans.m[i];
+    Material& m = o.material;
+    fin >> m.emissive[0] >> m.emissive[1] >> m.emissive[2];
+    fin >> m.brdf[0] >> m.brdf[1] >> m.brdf[2];
+    fin >> m.reflex_mode >> m.refract_mode;
+    fin >> m.refract_rate[0] >> m.refract_rate[1] >> m.refract_rate[2];
+    fin >> m.refract_albedo[0] >> m.refract_albedo[1] >> m.refract_albedo[2];
+    fin >> m.refract_index;
+    int is_normalize = 0;
+    fin >> is_normalize;
+    o.normalize = is_normalize != 0;
+    if (!fin) { err = path + ": malformed object record"; return false; }
+  }
+  return true;
+}
+
+bool write_render_args(const std::string& path, const RenderArgs& in) {
+  std::ofstream fout(path);
+  if (!fout.is_open()) return false;
+  fout.precision(9);
+  fout << in.eye[0] << ' ' << in.eye[1] << ' ' << in.eye[2] << std::endl;
+  for (int c = 0; c < 4; ++c) {
+    for (int r = 0; r < 4; ++r) fout << in.camera[4 * c + r] << ' ';
+    fout << std::endl;
+  }
+  fout << in.objects.size() << std::endl;
+  for (const RenderArgsObject& o : in.objects) {
+    fout << o.file << std::endl;
+    for (int c = 0; c < 4; ++c) {
+      for (int r = 0; r < 4; ++r) fout << o.trans.m[4 * c + r] << ' ';
+      fout << std::endl;
+    }
+    const Material& m = o.material;
+    fout << m.emissive[0] << ' ' << m.emissive[1] << ' ' << m.emissive[2] << std::endl;
+    fout << m.brdf[0] << ' ' << m.brdf[1] << ' ' << m.brdf[2] << std::endl;
+    fout << m.reflex_mode << std::endl << m.refract_mode << std::endl;
+    fout << m.refract_rate[0] << ' ' << m.refract_rate[1] << ' ' << m.refract_rate[2] << std::endl;
+    fout << m.refract_albedo[0] << ' ' << m.refract_albedo[1] << ' ' << m.refract_albedo[2] << std::endl;
+    fout << m.refract_index << std::endl;
+    fout << (o.normalize ? 1 : 0) << std::endl;
+  }
+  return (bool)fout;
+}
+
+// ------------------------------------------------------------ image output ----
+
+bool write_bmp(const std::string& path, const uint8_t* bgr, int width, int height) {
+  FILE* f = fopen(path.c_str(), "wb");
+  if (!f) return false;
+  uint32_t img = (uint32_t)width * (uint32_t)height * 3u;
+  unsigned char hdr[54];
+  memset(hdr, 0, sizeof hdr);
+  auto put32 = [&](int off, uint32_t v) { for (int i = 0; i < 4; ++i) hdr[off + i] = (unsigned char)(v >> (8 * i)); };
+  auto put16 = [&](int off, uint16_t v) { hdr[off] = (unsigned char)v; hdr[off + 1] = (unsigned char)(v >> 8); };
+  put16(0, 0x4d42);
+  put32(2, img + 54);
+  put32(10, 54);
+  put32(14, 40);
+  put32(18, (uint32_t)width);
+  put32(22, (uint32_t)height);
+  put16(26, 1);
+  put16(28, 24);
+  put32(34, img);
+  bool ok = fwrite(hdr, 1, 54, f) == 54 && fwrite(bgr, 1, img, f) == img;  // rows unpadded, as the reference
+  fclose(f);
+  return ok;
+}
+
+bool write_ppm(const std::string& path, const uint8_t* bgr, int width, int height) {
+  FILE* f = fopen(path.c_str(), "wb");
+  if (!f) return false;
+  fprintf(f, "P6\n%d %d\n255\n", width, height);
+  std::vector<uint8_t> row((size_t)3 * width);
+  for (int y = height - 1; y >= 0; --y) {
+    const uint8_t* src = bgr + (size_t)3 * y * width;
+    for (int x = 0; x < width; ++x) { row[3 * x] = src[3 * x + 2]; row[3 * x + 1] = src[3 * x + 1]; row[3 * x + 2] = src[3 * x]; }
+    fwrite(row.data(), 1, row.size(), f);
+  }
+  fclose(f);
+  return true;
+}
+
+bool write_pfm(const std::string& path, const float* rgb, int width, int height) {
+  FILE* f = fopen(path.c_str(), "wb");
+  if (!f) return false;
+  fprintf(f, "PF\n%d %d\n-1.0\n", width, height);
+  size_t n = (size_t)3 * width * height;
+  bool ok = fwrite(rgb, sizeof(float), n, f) == n;
+  fclose(f);
+  return ok;
+}
+
+// ---------------------------------------------------- built-in configurations ----
+
+static Material jade_material() {  // PathTrace.cpp:981-989
+  Material m;
+  for (int k = 0; k < 3; ++k) { m.brdf[k] = 0.02f; m.refract_rate[k] = 0.1f; m.refract_albedo[k] = 0.3f; }
+  m.reflex_mode = JADE_MIRROR;
+  m.refract_mode = JADE_SUB_SURFACE;
+  m.refract_index = 2.66f;
+  return m;
+}
+
+static Material diffuse_material(float r, float g, float b) {
+  Material m;
+  m.brdf[0] = r; m.brdf[1] = g; m.brdf[2] = b;
+  m.reflex_mode = JADE_DIFFUSE;
+  m.refract_mode = JADE_NO_REFRACT;
+  m.refract_index = 1.1f;
+  return m;
+}
+
+static void add_cornell(SceneBuilder& b, int sphere_freq) {
+  // Classic Cornell box data (549.6 x 548.8 x 559.2), scaled 0.01 and moved by
+  // (-2.796, -2.796, 0) as PathTrace.cpp:1028; materials PathTrace.cpp:1047-1066.
+  const float rot0[3] = {0, 0, 0}, tr[3] = {-2.796f, -2.796f, 0}, sc[3] = {0.01f, 0.01f, 0.01f};
+  Mat4 T = transform_matrix(rot0, tr, sc);
+  Material white = diffuse_material(0.72f, 0.72f, 0.72f);
+  Material red = diffuse_material(0.72f, 0, 0), green = diffuse_material(0, 0.72f, 0);
+  Mesh walls;  // floor, ceiling, back wall share one object like cornell_white_wall.obj
+  append(walls, make_quad(jv(552.8f, 0, 0), jv(0, 0, 0), jv(0, 0, 559.2f), jv(549.6f, 0, 559.2f)));
+  append(walls, make_quad(jv(556.0f, 548.8f, 0), jv(556.0f, 548.8f, 559.2f), jv(0, 548.8f, 559.2f), jv(0, 548.8f, 0)));
+  append(walls, make_quad(jv(549.6f, 0, 559.2f), jv(0, 0, 559.2f), jv(0, 548.8f, 559.2f), jv(556.0f, 548.8f, 559.2f)));
+  b.add_mesh(walls, white, T, false);
+  b.add_mesh(make_quad(jv(552.8f, 0, 0), jv(549.6f, 0, 559.2f), jv(556.0f, 548.8f, 559.2f), jv(556.0f, 548.8f, 0)), red, T, false);
+  b.add_mesh(make_quad(jv(0, 0, 559.2f), jv(0, 0, 0), jv(0, 548.8f, 0), jv(0, 548.8f, 559.2f)), green, T, false);
+  Material light = diffuse_material(0.78f, 0.78f, 0.78f);
+  for (int k = 0; k < 3; ++k) light.emissive[k] = 40.0f;
+  b.add_mesh(make_quad(jv(343.0f, 548.0f, 227.0f), jv(343.0f, 548.0f, 332.0f), jv(213.0f, 548.0f, 332.0f), jv(213.0f, 548.0f, 227.0f)),
+             light, T, false);
+  // two tessellated spheres (the reference has no sphere primitive)
+  Mesh ball = make_geodesic(sphere_freq);
+  const float sA[3] = {1.0f, 1.0f, 1.0f}, tA[3] = {-1.0f, -1.796f, 3.4f};
+  b.add_mesh(ball, jade_material(), transform_matrix(rot0, tA, sA), false);
+  const float sB[3] = {0.8f, 0.8f, 0.8f}, tB[3] = {1.2f, -1.996f, 1.7f};
+  b.add_mesh(ball, white, transform_matrix(rot0, tB, sB), false);
+}
+
+static void add_jade_scene(SceneBuilder& b, const Mesh& statue, bool dragon) {
+  // PathTrace.cpp:1002-1037: statue, light quad, mirror floor box.  The dragon
+  // uses the commented-out loong.obj placement (PathTrace.cpp:992).
+  const float rS[3] = {-90, 0, 0}, tS[3] = {0, -0.52f, 0.5f}, sS[3] = {0.3f, 0.3f, 0.3f};
+  const float rD[3] = {0, 0, 0}, tD[3] = {0.1f, -0.5f, 0.0f}, sD[3] = {0.7f, 0.7f, 0.7f};
+  b.add_mesh(statue, jade_material(), dragon ? transform_matrix(rD, tD, sD) : transform_matrix(rS, tS, sS), true);
+  Material light = diffuse_material(0.3f, 0.3f, 0.3f);
+  for (int k = 0; k < 3; ++k) light.emissive[k] = 1000.0f;
+  const float rL[3] = {0, 90, 90}, tL[3] = {-0.2f, 1.2f, 1.0f}, sL[3] = {1.5f, 0.5f, 1.5f};
+  // light.obj is git-ignored; stand-in: a unit quad in the xy-plane, which this
+  // transform turns into an upright panel beside the statue, edge-on to +z
+  Mesh lq = make_quad(jv(-0.5f, -0.5f, 0), jv(0.5f, -0.5f, 0), jv(0.5f, 0.5f, 0), jv(-0.5f, 0.5f, 0));
+  b.add_mesh(lq, light, transform_matrix(rL, tL, sL), true);
+  Material floor;
+  for (int k = 0; k < 3; ++k) { floor.brdf[k] = 0.3f; floor.refract_rate[k] = 0.7f; floor.refract_albedo[k] = 0.3f; }
+  floor.reflex_mode = JADE_MIRROR;
+  floor.refract_mode = JADE_NO_REFRACT;
+  floor.refract_index = 1.1f;
+  const float r0[3] = {0, 0, 0}, tF[3] = {0, -0.5625f, 0}, sF[3] = {12, 0.125f, 12};
+  b.add_mesh(make_box(), floor, transform_matrix(r0, tF, sF), true);
+}
+
+bool make_config(const std::string& name, SceneBuilder& b, Config& cfg, std::string& err) {
+  cfg.name = name;
+  if (name == "tiny" || name == "C1") {
+    // C1: Cornell box, 5 walls + light quad + 2 spheres, 256x256, 64 spp.
+    // "tiny" is the same scene with coarser spheres at 32x32, 4 spp (goldens).
+    bool tiny = name == "tiny";
+    add_cornell(b, tiny ? 3 : 8);
+    b.set_env(make_env_constant(0, 0, 0));
+    cfg.width = cfg.height = tiny ? 32 : 256;
+    cfg.spp = tiny ? 4 : 64;
+    const float ctr[3] = {0, 0, 2.8f};
+    camera_orbit(8.0f, 0.0f, 180.0f, ctr, cfg.eye, cfg.camera);  // r = 8, PathTrace.cpp:1027
+    return true;
+  }
+  if (name == "tinyjade") {
+    // small jade scene for goldens: statue at 20*6^2 = 720 triangles
+    add_jade_scene(b, make_statue(6, 7u, 0), false);
+    b.set_env(make_env_sky(64, 32));
+    cfg.width = cfg.height = 32;
+    cfg.spp = 4;
+    const float ctr[3] = {0.26f, -1.28f, 0.0f};
+    camera_orbit(0.8f, 8.0f, 10.0f, ctr, cfg.eye, cfg.camera);
+    return true;
+  }
+  if (name == "C2" || name == "C3" || name == "C4") {
+    add_jade_scene(b, make_statue(59, 20211013u, 0), false);  // 20*59^2 = 69,620 triangles
+    b.set_env(make_env_sky(1024, 512));
+    if (name == "C2") { cfg.width = cfg.height = 512; cfg.spp = 256; }
+    else { cfg.width = 1920; cfg.height = 1080; cfg.spp = 4096; }
+    // The GL host starts at r = 4, angles 0 (PathTrace.cpp:209-211) and the
+    // user frames the statue with the arrow / WASD / H / N keys (:737-801);
+    // this is such a framing, fixed here so every run sees the same image.
+    const float ctr[3] = {0.26f, -1.28f, 0.0f};
+    camera_orbit(0.8f, 8.0f, 10.0f, ctr, cfg.eye, cfg.camera);
+    return true;
+  }
+  if (name == "C5") {
+    add_jade_scene(b, make_statue(209, 20211013u, 1), true);  // 20*209^2 = 873,620 triangles
+    b.set_env(make_env_sky(1024, 512));
+    cfg.width = 3840; cfg.height = 2160; cfg.spp = 8192;
+    const float ctr[3] = {0.1f, -0.35f, 0.0f};
+    camera_orbit(1.3f, 14.0f, 25.0f, ctr, cfg.eye, cfg.camera);
+    return true;
+  }
+  err = "unknown config '" + name + "' (tiny, tinyjade, C1, C2, C3, C4, C5)";
+  return false;
+}
+
+}  // namespace jadehost
