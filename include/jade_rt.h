@@ -128,6 +128,10 @@ typedef struct jade_stats {
   uint64_t shaded_hits;    /* H: pathTracing loop iterations (vertices shaded) */
   uint64_t samples;        /* pixels * spp rendered by this call */
   double kernel_ms;        /* device (or CPU wall) time inside the integrator */
+  /* the dominant kernel alone (HIP: k_trace, timed with HIP events on its own
+   * stream, summed over launches; oracle: 0) — feeds the roofline figure */
+  double trace_ms;
+  uint64_t trace_launches;
 } jade_stats;
 
 typedef struct jade_scene jade_scene; /* opaque */

@@ -65,6 +65,7 @@ class Stats(C.Structure):
         ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64),
         ("shaded_hits", C.c_uint64), ("samples", C.c_uint64),
         ("kernel_ms", C.c_double),
+        ("trace_ms", C.c_double), ("trace_launches", C.c_uint64),
     ]
 
     def as_dict(self):

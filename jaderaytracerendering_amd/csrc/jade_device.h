@@ -1,0 +1,113 @@
+// jade_device.h — device-side data layout of the HIP module (gfx950).
+//
+// The boundary arrays (include/jade_rt.h) arrive in the reference's AoS
+// layouts (Triangle_cu 112 B, BVHNode_cu 40 B).  The traversal kernel does not
+// read those: jade_scene_create re-lays the geometry out as
+//
+//   node records   64 B per INTERNAL node, children's boxes stored in the
+//                  parent:  float4 {L.aa.xyz, L.bb.x} {L.bb.yz, R.aa.xy}
+//                  {R.aa.z, R.bb.xyz} + uint4 {left_ref, right_ref, 0, 0}
+//                  -> one visit = 4 x 16-B loads from one 64-B aligned line,
+//                  instead of the reference's 3 x 40-B records (parent, and
+//                  each child read again when popped: PathTrace.cu:809/826/830)
+//   child refs     internal: index into the compacted node array;
+//                  leaf: 0x80000000 | first_triangle << 4 | n  (n <= 15);
+//                  JADE_REF_NONE for the reference's "child 0"
+//   vertex records 48 B per triangle: three float4 {p.xyz, pad}; the 76 B of
+//                  material data never enter the traversal cache footprint
+//
+// Shading reads the untouched 112-B records (they are needed once per
+// shaded vertex, not once per intersection test).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "jade_fpmath.h"
+#include "jade_rt.h"
+
+#define JADE_REF_LEAF 0x80000000u
+#define JADE_REF_NONE 0x7fffffffu
+#define JADE_MAX_LEAF 15
+#define JADE_INF_F 2147483647.0f /* #define INF, PathTrace.cu:23 */
+
+#define JADE_LDS_STACK 32 /* traversal stack entries kept in LDS per lane */
+#define JADE_TRACE_BLOCK 256
+
+struct DevScene {
+  const float4* nodes;        // 4 x float4 per internal node
+  const float4* tverts;       // 3 x float4 per triangle (BVH order)
+  const jade_triangle* tris;  // shading records (BVH order)
+  const int32_t* emit;
+  const int32_t* mapping;
+  const float* prefix;
+  const jade_obj_seg* segs;
+  const float* env;           // interleaved RGB, row 0 = top
+  int32_t env_w, env_h;
+  int32_t n_tris, n_emit;
+  uint32_t root_ref;
+};
+
+// Per-pixel path state, structure of arrays over the rank's owned pixels
+// (pixel p = owned_tile * 256 + ly * 16 + lx).  `nslots` = n_emit + 2 ray
+// slots per pixel: [0, n_emit) shadow rays, n_emit = environment-visibility
+// ray, n_emit + 1 = indirect ray; single-ray stages use slot 0.
+struct PathState {
+  int32_t npix;
+  int32_t nslots;
+  uint32_t* rng;        // Wang-hash state
+  uint32_t* done;       // samples finished
+  uint32_t* stage;      // stage | depth << 8 | flags << 16
+  float* sum;           // [3][npix] running radiance sum over samples
+  float* thr;           // [3][npix] throughput (product of pushed rates)
+  float* acc;           // [3][npix] radiance gathered along the current path
+  float* le;            // [3][npix] emission at the primary hit
+  int32_t* obj;         // current vertex: triangle index
+  float* src;           // [3][npix] current vertex position
+  float* out;           // [3][npix] direction back toward the previous vertex
+  float* org;           // [3][npix] origin shared by this pixel's pending rays
+  int32_t* skip;        // source triangle of the pending rays
+  float* aux;           // [3][npix] BSSRDF profile / refraction attenuation
+  int32_t* auxi;        // refraction: iteration counter
+  float* dir;           // [3][nslots][npix] pending ray directions
+  int32_t* hit;         // [nslots][npix] -2 inactive, -1 miss, >= 0 triangle
+  float* hpt;           // [3][nslots][npix] hit points
+};
+
+enum : uint32_t {
+  ST_IDLE = 0,       // between samples
+  ST_PRIMARY = 1,    // camera ray in flight
+  ST_VERTEX = 2,     // at a surface vertex, bounce not yet sampled
+  ST_DIFFUSE = 3,    // diffuse / SSS-diffuse rays in flight
+  ST_BSSRDF = 4,
+  ST_MIRROR = 5,
+  ST_REFRACT_LOOP = 6,
+  ST_REFRACT_EXIT = 7,
+  ST_INVALID = 255,  // pixel outside the image (edge tiles)
+};
+#define STF_SSS 1u      /* ST_DIFFUSE: SSS-diffuse variant (albedo, x4) */
+#define STF_RR 2u       /* the indirect ray was issued (RR passed) */
+#define STF_FULLREFLEX 4u
+
+struct RenderConst {
+  int32_t width, height;
+  int32_t tiles_x;
+  uint32_t frame;
+  float eye[3];
+  float cam[16];
+  double two_over_w, two_over_h, aspect;
+};
+
+struct DevCounters {
+  unsigned long long rays_primary, rays_secondary, nodes_visited, tris_tested, shaded_hits, samples;
+  unsigned long long active_paths;  // pixels still working after the last shade pass
+};
+
+static __device__ __forceinline__ jvec3 ld3(const float* a, int npix, int p) {
+  return jv(a[p], a[npix + p], a[2 * npix + p]);
+}
+static __device__ __forceinline__ void st3(float* a, int npix, int p, jvec3 v) {
+  a[p] = v.x;
+  a[npix + p] = v.y;
+  a[2 * npix + p] = v.z;
+}
+static __device__ __forceinline__ jvec3 V3(const float* p) { return jv(p[0], p[1], p[2]); }

@@ -1,0 +1,786 @@
+// jade_hip.hip — libjade_hip.so: the jade_rt.h C ABI on MI355X (gfx950).
+//
+// Replaces PathTrace.cu:1618-1741 (upload, constants, RNG init, the single
+// render_pixel launch, sync, download).  Kernel structure (one HIP stream):
+//
+//   k_init     seeds the per-pixel Wang-hash states, clears the sums
+//   k_shade    one lane per owned pixel: fold last pass's hit results into the
+//              path, start the next sample when a path ends, sample the next
+//              bounce, emit its rays into a compacted queue (wave prefix sum +
+//              one atomic per wave)
+//   k_trace    persistent workgroups pull 64-ray batches from the queue and run
+//              the BVH traversal (jade_trace.h) — the dominant kernel
+//   k_resolve  mean, ACES, gamma, BGR8 pack (PathTrace.cu:1457-1473)
+//
+// shade/trace alternate until a shade pass emits nothing (every pixel has
+// finished its samples).  There is no CPU fallback: if HIP is unavailable the
+// entry points return JADE_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "jade_device.h"
+#include "jade_shade.h"
+#include "jade_trace.h"
+
+// ------------------------------------------------------------------ kernels --
+
+struct QueueCtl {
+  uint32_t count;  // rays emitted by the last shade pass
+  uint32_t next;   // next unclaimed queue entry (trace)
+  uint32_t fp_bad; // jade_fp_selftest result (checked once)
+  uint32_t pad;
+};
+
+static __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t* total) {
+  const int lane = threadIdx.x & 63;
+  uint32_t x = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    uint32_t y = __shfl_up(x, off, 64);
+    if (lane >= off) x += y;
+  }
+  *total = __shfl(x, 63, 64);
+  return x - v;
+}
+
+static __device__ __forceinline__ unsigned long long wave_sum_u32(uint32_t v) {
+  unsigned long long x = v;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+  return x;  // valid in lane 0
+}
+
+__global__ void k_selftest(QueueCtl* q, float one) { q->fp_bad = (uint32_t)jade_fp_selftest(one); }
+
+__global__ void k_init(PathState P, RenderConst R, const int32_t* tile_ids) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P.npix) return;
+  int t = p >> 8, l = p & 255;
+  int tid = tile_ids[t];
+  int x = (tid % R.tiles_x) * JADE_TILE_SIZE + (l & 15);
+  int y = (tid / R.tiles_x) * JADE_TILE_SIZE + (l >> 4);
+  bool valid = x < R.width && y < R.height;
+  P.rng[p] = jade_rng_seed((uint32_t)x, (uint32_t)y, R.frame);
+  P.done[p] = 0;
+  P.stage[p] = valid ? ST_IDLE : ST_INVALID;
+  st3(P.sum, P.npix, p, jv(0, 0, 0));
+}
+
+__global__ __launch_bounds__(256) void k_shade(DevScene S, PathState P, RenderConst R, const int32_t* tile_ids,
+                                               uint32_t target_spp, uint32_t* queue, QueueCtl* qc, DevCounters* ctr) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int npix = P.npix;
+  ShadeCtx c;
+  c.n_emit_rays = 0;
+  c.c_primary = c.c_secondary = c.c_shaded = c.c_samples = 0;
+  uint32_t st = ST_INVALID;
+  if (p < npix) st = P.stage[p] & 255u;
+  if (st != ST_INVALID) {
+    const uint32_t word = P.stage[p];
+    const Px px(P, p);
+    c.rng = P.rng[p];
+    c.depth = (word >> 8) & 255u;
+    c.flags = word >> 16;
+    c.stage = st;
+    c.thr = ld3(P.thr, npix, p);
+    c.acc = ld3(P.acc, npix, p);
+    c.le = ld3(P.le, npix, p);
+    c.obj = P.obj[p];
+    c.src = ld3(P.src, npix, p);
+    c.out = ld3(P.out, npix, p);
+    jvec3 sum = ld3(P.sum, npix, p);
+    uint32_t done = P.done[p];
+    jvec3 l_final;
+    bool finished = false;  // a sample ended: colour in `color`
+    jvec3 color = jv(0, 0, 0);
+
+    // (a) fold in the results of the rays issued by the previous pass
+    if (st == ST_PRIMARY) {
+      int h = px.hit(0);
+      jvec3 d = px.dir(0);
+      if (h < 0) {
+        color = sample_hdr(S, d);  // PathTrace.cu:1443-1445
+        finished = true;
+      } else {
+        c.le = V3(S.tris[h].emissive);
+        c.thr = jv(1, 1, 1);
+        c.acc = jv(0, 0, 0);
+        c.depth = 0;
+        c.obj = h;
+        c.src = px.hpt(0);
+        c.out = jv_neg(d);
+        st = ST_VERTEX;
+      }
+    } else if (st >= ST_DIFFUSE && st <= ST_REFRACT_EXIT) {
+      int r = consume(S, px, c, &l_final);
+      if (r == CONSUME_VERTEX) {
+        st = ST_VERTEX;
+      } else if (r == CONSUME_EMITTED) {
+        st = c.stage;
+      } else {
+        if (r == CONSUME_END) color = jv_add(c.le, jv_add(c.acc, jv_mul(c.thr, l_final)));
+        else color = c.le;  // pathTracing returned 0
+        finished = true;
+      }
+    }
+    // (b) advance until this pixel has rays in flight or no samples left
+    for (;;) {
+      if (finished) {
+        sum = jv_add(sum, color);  // final_result = final_result + color, :1454
+        done += 1;
+        c.c_samples += 1;
+        finished = false;
+        st = ST_IDLE;
+      }
+      if (st == ST_VERTEX) {
+        if (begin_bounce(S, px, c, &l_final)) {
+          st = c.stage;
+          break;
+        }
+        color = jv_add(c.le, jv_add(c.acc, jv_mul(c.thr, l_final)));
+        finished = true;
+        continue;
+      }
+      if (st == ST_IDLE) {
+        if (done >= target_spp) break;
+        // camera ray, PathTrace.cu:1428-1437
+        int t = p >> 8, l = p & 255;
+        int tid = tile_ids[t];
+        int x = (tid % R.tiles_x) * JADE_TILE_SIZE + (l & 15);
+        int y = (tid / R.tiles_x) * JADE_TILE_SIZE + (l >> 4);
+        float fx = (float)x + jade_rand(&c.rng);
+        double lo = -1.0 + R.two_over_w * ((double)fx - 0.5);
+        float left_offset = (float)(lo * R.aspect);
+        float fy = (float)y + jade_rand(&c.rng);
+        float up_offset = (float)(-1.0 + R.two_over_h * ((double)fy - 0.5));
+        jvec3 dir = jade_transform(jv(left_offset, up_offset, -1.5f), 0.0f, R.cam);
+        dir = jv_normalize(dir);
+        st3(P.org, npix, p, jv(R.eye[0], R.eye[1], R.eye[2]));
+        P.skip[p] = -1;
+        px.set_dir(0, dir);
+        px.set_hit(0, -1);
+        c.n_emit_rays = 1;
+        c.c_primary += 1;
+        st = ST_PRIMARY;
+        break;
+      }
+      break;  // a pending stage that just emitted (refraction loop)
+    }
+    if (st != ST_PRIMARY) c.c_secondary += (uint32_t)c.n_emit_rays;
+    P.rng[p] = c.rng;
+    P.done[p] = done;
+    P.stage[p] = st | (c.depth << 8) | (c.flags << 16);
+    st3(P.sum, npix, p, sum);
+    st3(P.thr, npix, p, c.thr);
+    st3(P.acc, npix, p, c.acc);
+    st3(P.le, npix, p, c.le);
+    P.obj[p] = c.obj;
+    st3(P.src, npix, p, c.src);
+    st3(P.out, npix, p, c.out);
+  }
+
+  // (c) queue the emitted rays: wave-level exclusive scan, one atomic per wave
+  const int lane = threadIdx.x & 63;
+  uint32_t total;
+  uint32_t off = wave_excl_scan((uint32_t)c.n_emit_rays, &total);
+  uint32_t base = 0;
+  if (total) {
+    if (lane == 0) base = atomicAdd(&qc->count, total);
+    base = __shfl(base, 0, 64);
+    if (c.n_emit_rays) {
+      const int used = (st == ST_DIFFUSE || st == ST_BSSRDF) ? P.nslots : 1;
+      uint32_t w = base + off;
+      for (int k = 0; k < used; ++k)
+        if (P.hit[(size_t)k * npix + p] == -1) queue[w++] = (uint32_t)k * (uint32_t)npix + (uint32_t)p;
+    }
+  }
+  unsigned long long s0 = wave_sum_u32(c.c_primary), s1 = wave_sum_u32(c.c_secondary), s2 = wave_sum_u32(c.c_shaded),
+                     s3 = wave_sum_u32(c.c_samples);
+  if (lane == 0) {
+    if (s0) atomicAdd(&ctr->rays_primary, s0);
+    if (s1) atomicAdd(&ctr->rays_secondary, s1);
+    if (s2) atomicAdd(&ctr->shaded_hits, s2);
+    if (s3) atomicAdd(&ctr->samples, s3);
+  }
+}
+
+__global__ __launch_bounds__(JADE_TRACE_BLOCK) void k_trace(DevScene S, PathState P, const uint32_t* queue, QueueCtl* qc,
+                                                           uint32_t* spill, DevCounters* ctr) {
+  __shared__ uint32_t lds_stack[JADE_LDS_STACK * JADE_TRACE_BLOCK];
+  const int lane = threadIdx.x & 63;
+  const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
+  LdsStack stk;
+  stk.lds = lds_stack + threadIdx.x;
+  stk.stride_lds = JADE_TRACE_BLOCK;
+  stk.spill = spill + gtid;
+  stk.stride_spill = gridDim.x * blockDim.x;
+  const uint32_t n = qc->count;
+  const int npix = P.npix;
+  const size_t plane = (size_t)P.nslots * npix;
+  uint32_t V = 0, T = 0;
+  for (;;) {
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&qc->next, 64u);
+    base = __shfl(base, 0, 64);
+    if (base >= n) break;
+    uint32_t i = base + lane;
+    if (i < n) {
+      uint32_t e = queue[i];
+      uint32_t k = e / (uint32_t)npix, p = e - k * (uint32_t)npix;
+      jvec3 o = ld3(P.org, npix, p);
+      const float* db = P.dir + (size_t)k * npix + p;
+      jvec3 d = jv(db[0], db[plane], db[2 * plane]);
+      TraceHit h = trace_ray(S, o, d, P.skip[p], stk, V, T);
+      P.hit[(size_t)k * npix + p] = h.index;
+      float* hb = P.hpt + (size_t)k * npix + p;
+      hb[0] = h.point.x;
+      hb[plane] = h.point.y;
+      hb[2 * plane] = h.point.z;
+    }
+  }
+  unsigned long long sv = wave_sum_u32(V), stt = wave_sum_u32(T);
+  if (lane == 0) {
+    if (sv) atomicAdd(&ctr->nodes_visited, sv);
+    if (stt) atomicAdd(&ctr->tris_tested, stt);
+  }
+}
+
+// ACESToneMapping + gamma + BGR pack, PathTrace.cu:680-682, 1457-1473.
+__global__ void k_resolve(PathState P, float inv_spp, float* out_rgb, uint8_t* out_bgr) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P.npix) return;
+  bool valid = (P.stage[p] & 255u) != ST_INVALID;
+  jvec3 m = jv(0, 0, 0);
+  if (valid) {
+    jvec3 s = ld3(P.sum, P.npix, p);
+    m = jv(s.x * inv_spp, s.y * inv_spp, s.z * inv_spp);
+  }
+  if (out_rgb) {
+    out_rgb[3 * (size_t)p] = m.x;
+    out_rgb[3 * (size_t)p + 1] = m.y;
+    out_rgb[3 * (size_t)p + 2] = m.z;
+  }
+  if (out_bgr) {
+    float v[3] = {m.x, m.y, m.z};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float x = v[k];
+      float num = x * (x * 2.51f + 0.03f);
+      float den = x * (x * 2.43f + 0.59f) + 0.14f;
+      x = num / den;
+      x = jade_powf(x, (float)(1.0 / 2.2));
+      x = x * 255.0f;
+      x = x > 255 ? 255 : x;
+      v[k] = x;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float x = v[2 - k];
+      out_bgr[3 * (size_t)p + k] = (valid && x >= 0.0f) ? (uint8_t)x : (uint8_t)0;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- host side --
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess)                                                                  \
+      return fail(e_ == hipErrorOutOfMemory ? JADE_ERR_NOMEM : JADE_ERR_DEVICE,            \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                      \
+  } while (0)
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t n) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+    bytes = n;
+    return hipMalloc(&p, n ? n : 16);
+  }
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct jade_scene {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  DevScene dev{};
+  DevBuf b_nodes, b_tverts, b_tris, b_emit, b_mapping, b_prefix, b_segs, b_env;
+  int n_emit = 0;
+  int bvh_depth = 0;
+  // render state
+  bool have_rp = false;
+  jade_render_params rp{};
+  RenderConst rc{};
+  PathState ps{};
+  DevBuf b_state, b_tiles, b_queue, b_ctl, b_ctr, b_spill, b_out_rgb, b_out_bgr;
+  std::vector<int32_t> tile_ids;
+  int trace_blocks = 0;
+  int64_t spp_done = 0;
+  ~jade_scene() {
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+template <class T>
+static hipError_t upload(DevBuf& b, const T* src, size_t count) {
+  hipError_t e = b.alloc(sizeof(T) * count);
+  if (e != hipSuccess) return e;
+  if (count) e = hipMemcpy(b.p, src, sizeof(T) * count, hipMemcpyHostToDevice);
+  return e;
+}
+
+extern "C" {
+
+int jade_abi_version(void) { return JADE_ABI_VERSION; }
+const char* jade_backend_name(void) { return "hip-gfx950"; }
+const char* jade_last_error(void) { return g_err.c_str(); }
+
+int jade_device_count(int* n) {
+  if (!n) return fail(JADE_ERR_INVALID, "null argument");
+  *n = 0;
+  HIP_TRY(hipGetDeviceCount(n));
+  return JADE_OK;
+}
+
+int jade_owned_tile_count(int32_t width, int32_t height, int32_t rank, int32_t nranks) {
+  if (width <= 0 || height <= 0 || nranks <= 0 || rank < 0 || rank >= nranks) return -1;
+  int tx = (width + JADE_TILE_SIZE - 1) / JADE_TILE_SIZE, ty = (height + JADE_TILE_SIZE - 1) / JADE_TILE_SIZE;
+  int total = tx * ty;
+  return (total - rank + nranks - 1) / nranks;
+}
+
+static int validate_desc(const jade_scene_desc* d, int* depth_out) {
+  if (d->abi_version != JADE_ABI_VERSION) return fail(JADE_ERR_INVALID, "abi_version mismatch");
+  if (d->n_triangles <= 0 || d->n_nodes < 2 || !d->triangles || !d->nodes)
+    return fail(JADE_ERR_INVALID, "scene needs triangles and a BVH (dummy node 0 + root 1)");
+  if (d->n_triangles >= (1 << 27)) return fail(JADE_ERR_UNSUPPORTED, "more than 2^27 triangles");
+  if (d->n_emit < 0 || (d->n_emit > 0 && !d->emit_indices)) return fail(JADE_ERR_INVALID, "bad emitter list");
+  if (!d->index_mapping || !d->prefix_area || d->n_objects <= 0 || !d->obj_segs)
+    return fail(JADE_ERR_INVALID, "missing mapping / prefix areas / object segments");
+  if (d->env_width <= 0 || d->env_height <= 0 || !d->env_rgb) return fail(JADE_ERR_INVALID, "missing environment map");
+  for (int i = 0; i < d->n_emit; ++i)
+    if (d->emit_indices[i] < 0 || d->emit_indices[i] >= d->n_triangles) return fail(JADE_ERR_INVALID, "emitter index out of range");
+  for (int i = 0; i < d->n_triangles; ++i) {
+    if (d->index_mapping[i] < 0 || d->index_mapping[i] >= d->n_triangles) return fail(JADE_ERR_INVALID, "index_mapping out of range");
+    if (d->triangles[i].obj_idx < 0 || d->triangles[i].obj_idx >= d->n_objects) return fail(JADE_ERR_INVALID, "obj_idx out of range");
+  }
+  for (int i = 0; i < d->n_objects; ++i)
+    if (d->obj_segs[i].begin_idx < 0 || d->obj_segs[i].end_idx >= d->n_triangles || d->obj_segs[i].begin_idx > d->obj_segs[i].end_idx)
+      return fail(JADE_ERR_INVALID, "object segment out of range");
+  // walk the tree: ranges, cycles (visit budget), depth <= stack capacity - 1
+  std::vector<std::pair<int, int>> st;
+  st.push_back({1, 1});
+  int64_t budget = 4 * (int64_t)d->n_nodes + 8;
+  int depth = 0;
+  while (!st.empty()) {
+    auto [id, dp] = st.back();
+    st.pop_back();
+    if (--budget < 0) return fail(JADE_ERR_UNSUPPORTED, "BVH malformed (cycle)");
+    if (dp > JADE_BVH_STACK_CAPACITY - 1) return fail(JADE_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
+    depth = std::max(depth, dp);
+    const jade_bvh_node& nd = d->nodes[id];
+    if (nd.n > 0) {
+      if (nd.index < 0 || (int64_t)nd.index + nd.n > d->n_triangles) return fail(JADE_ERR_INVALID, "leaf range out of bounds");
+      if (nd.n > JADE_MAX_LEAF) return fail(JADE_ERR_UNSUPPORTED, "leaf with more than 15 triangles");
+      continue;
+    }
+    if (nd.left < 0 || nd.left >= d->n_nodes || nd.right < 0 || nd.right >= d->n_nodes)
+      return fail(JADE_ERR_INVALID, "child index out of range");
+    if (nd.left > 0) st.push_back({nd.left, dp + 1});
+    if (nd.right > 0) st.push_back({nd.right, dp + 1});
+  }
+  *depth_out = depth;
+  return JADE_OK;
+}
+
+int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out) {
+  if (!d || !out) return fail(JADE_ERR_INVALID, "null argument");
+  int depth = 0;
+  int rc = validate_desc(d, &depth);
+  if (rc) return rc;
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device_id < 0 || device_id >= ndev) return fail(JADE_ERR_DEVICE, "no such HIP device");
+  HIP_TRY(hipSetDevice(device_id));
+
+  // re-lay the BVH: compact the internal nodes, children's boxes in the parent
+  const int nN = d->n_nodes;
+  std::vector<int32_t> compact(nN, -1);
+  int n_internal = 0;
+  for (int i = 1; i < nN; ++i)
+    if (d->nodes[i].n <= 0) compact[i] = n_internal++;
+  auto ref_of = [&](int child) -> uint32_t {
+    if (child <= 0) return JADE_REF_NONE;
+    const jade_bvh_node& c = d->nodes[child];
+    if (c.n > 0) return JADE_REF_LEAF | ((uint32_t)c.index << 4) | (uint32_t)c.n;
+    return (uint32_t)compact[child];
+  };
+  std::vector<float4> nodes((size_t)4 * std::max(n_internal, 1));
+  for (int i = 1; i < nN; ++i) {
+    const jade_bvh_node& nd = d->nodes[i];
+    if (nd.n > 0) continue;
+    float la[3] = {0, 0, 0}, lb[3] = {0, 0, 0}, ra[3] = {0, 0, 0}, rb[3] = {0, 0, 0};
+    if (nd.left > 0) { memcpy(la, d->nodes[nd.left].aa, 12); memcpy(lb, d->nodes[nd.left].bb, 12); }
+    if (nd.right > 0) { memcpy(ra, d->nodes[nd.right].aa, 12); memcpy(rb, d->nodes[nd.right].bb, 12); }
+    float4* o = &nodes[(size_t)4 * compact[i]];
+    o[0] = make_float4(la[0], la[1], la[2], lb[0]);
+    o[1] = make_float4(lb[1], lb[2], ra[0], ra[1]);
+    o[2] = make_float4(ra[2], rb[0], rb[1], rb[2]);
+    uint32_t refs[4] = {ref_of(nd.left), ref_of(nd.right), 0u, 0u};
+    memcpy(&o[3], refs, 16);
+  }
+  std::vector<float4> tverts((size_t)3 * d->n_triangles);
+  for (int i = 0; i < d->n_triangles; ++i) {
+    const jade_triangle& t = d->triangles[i];
+    tverts[3 * (size_t)i] = make_float4(t.p1[0], t.p1[1], t.p1[2], 0.0f);
+    tverts[3 * (size_t)i + 1] = make_float4(t.p2[0], t.p2[1], t.p2[2], 0.0f);
+    tverts[3 * (size_t)i + 2] = make_float4(t.p3[0], t.p3[1], t.p3[2], 0.0f);
+  }
+
+  jade_scene* s = new (std::nothrow) jade_scene();
+  if (!s) return fail(JADE_ERR_NOMEM, "out of memory");
+  s->device = device_id;
+  s->n_emit = d->n_emit;
+  s->bvh_depth = depth;
+  hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = upload(s->b_nodes, nodes.data(), nodes.size());
+  if (e == hipSuccess) e = upload(s->b_tverts, tverts.data(), tverts.size());
+  if (e == hipSuccess) e = upload(s->b_tris, d->triangles, (size_t)d->n_triangles);
+  if (e == hipSuccess) e = upload(s->b_emit, d->emit_indices, (size_t)d->n_emit);
+  if (e == hipSuccess) e = upload(s->b_mapping, d->index_mapping, (size_t)d->n_triangles);
+  if (e == hipSuccess) e = upload(s->b_prefix, d->prefix_area, (size_t)d->n_triangles);
+  if (e == hipSuccess) e = upload(s->b_segs, d->obj_segs, (size_t)d->n_objects);
+  if (e == hipSuccess) e = upload(s->b_env, d->env_rgb, (size_t)3 * d->env_width * d->env_height);
+  if (e == hipSuccess) e = s->b_ctl.alloc(sizeof(QueueCtl));
+  if (e == hipSuccess) e = s->b_ctr.alloc(sizeof(DevCounters));
+  if (e != hipSuccess) {
+    delete s;
+    return fail(e == hipErrorOutOfMemory ? JADE_ERR_NOMEM : JADE_ERR_DEVICE, std::string("scene upload: ") + hipGetErrorString(e));
+  }
+  s->dev.nodes = s->b_nodes.as<float4>();
+  s->dev.tverts = s->b_tverts.as<float4>();
+  s->dev.tris = s->b_tris.as<jade_triangle>();
+  s->dev.emit = s->b_emit.as<int32_t>();
+  s->dev.mapping = s->b_mapping.as<int32_t>();
+  s->dev.prefix = s->b_prefix.as<float>();
+  s->dev.segs = s->b_segs.as<jade_obj_seg>();
+  s->dev.env = s->b_env.as<float>();
+  s->dev.env_w = d->env_width;
+  s->dev.env_h = d->env_height;
+  s->dev.n_tris = d->n_triangles;
+  s->dev.n_emit = d->n_emit;
+  s->dev.root_ref = ref_of(1);
+
+  // the arithmetic contract of jade_fpmath.h, checked on the device once
+  hipLaunchKernelGGL(k_selftest, dim3(1), dim3(1), 0, s->stream, s->b_ctl.as<QueueCtl>(), 1.0f);
+  QueueCtl qc{};
+  e = hipMemcpyAsync(&qc, s->b_ctl.p, sizeof qc, hipMemcpyDeviceToHost, s->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+  if (e != hipSuccess || qc.fp_bad) {
+    std::string m = e != hipSuccess ? std::string("selftest: ") + hipGetErrorString(e)
+                                    : "device code was built with FP contraction on (see include/jade_fpmath.h)";
+    delete s;
+    return fail(JADE_ERR_DEVICE, m);
+  }
+  // persistent trace grid: blocks per CU bounded by the LDS stack (32 KB/block)
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+  int per_cu = 0;
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace, JADE_TRACE_BLOCK, 0);
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu > 8) per_cu = 8;
+  s->trace_blocks = prop.multiProcessorCount * per_cu;
+  *out = s;
+  return JADE_OK;
+}
+
+void jade_scene_destroy(jade_scene* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  delete s;
+}
+
+static int setup_state(jade_scene* s, int npix, int nslots) {
+  // carve every per-pixel array out of one allocation
+  size_t words = 0;
+  auto take = [&](size_t n) { size_t o = words; words += (n + 63) & ~(size_t)63; return o; };
+  const size_t N = (size_t)npix, K = (size_t)nslots;
+  size_t o_rng = take(N), o_done = take(N), o_stage = take(N), o_sum = take(3 * N), o_thr = take(3 * N), o_acc = take(3 * N),
+         o_le = take(3 * N), o_obj = take(N), o_src = take(3 * N), o_out = take(3 * N), o_org = take(3 * N), o_skip = take(N),
+         o_aux = take(3 * N), o_auxi = take(N), o_dir = take(3 * K * N), o_hit = take(K * N), o_hpt = take(3 * K * N);
+  HIP_TRY(s->b_state.alloc(words * 4));
+  HIP_TRY(hipMemsetAsync(s->b_state.p, 0, words * 4, s->stream));
+  uint32_t* b = s->b_state.as<uint32_t>();
+  PathState& P = s->ps;
+  P.npix = npix;
+  P.nslots = nslots;
+  P.rng = b + o_rng; P.done = b + o_done; P.stage = b + o_stage;
+  P.sum = (float*)(b + o_sum); P.thr = (float*)(b + o_thr); P.acc = (float*)(b + o_acc); P.le = (float*)(b + o_le);
+  P.obj = (int32_t*)(b + o_obj); P.src = (float*)(b + o_src); P.out = (float*)(b + o_out); P.org = (float*)(b + o_org);
+  P.skip = (int32_t*)(b + o_skip); P.aux = (float*)(b + o_aux); P.auxi = (int32_t*)(b + o_auxi);
+  P.dir = (float*)(b + o_dir); P.hit = (int32_t*)(b + o_hit); P.hpt = (float*)(b + o_hpt);
+  HIP_TRY(s->b_queue.alloc(K * N * 4));
+  if (!s->b_spill.p)
+    HIP_TRY(s->b_spill.alloc((size_t)(JADE_BVH_STACK_CAPACITY - JADE_LDS_STACK) * s->trace_blocks * JADE_TRACE_BLOCK * 4));
+  return JADE_OK;
+}
+
+int jade_render_begin(jade_scene* s, const jade_render_params* rp) {
+  if (!s || !rp) return fail(JADE_ERR_INVALID, "null argument");
+  if (rp->width <= 0 || rp->height <= 0 || rp->tile_nranks <= 0 || rp->tile_rank < 0 || rp->tile_rank >= rp->tile_nranks)
+    return fail(JADE_ERR_INVALID, "bad image size or tile partition");
+  HIP_TRY(hipSetDevice(s->device));
+  const int tx = (rp->width + JADE_TILE_SIZE - 1) / JADE_TILE_SIZE, ty = (rp->height + JADE_TILE_SIZE - 1) / JADE_TILE_SIZE;
+  s->tile_ids.clear();
+  for (int id = rp->tile_rank; id < tx * ty; id += rp->tile_nranks) s->tile_ids.push_back(id);
+  const int nslots = s->n_emit + 2;
+  const int64_t npix64 = (int64_t)s->tile_ids.size() * 256;
+  if (npix64 * nslots >= ((int64_t)1 << 32)) return fail(JADE_ERR_UNSUPPORTED, "pixels x (emitters + 2) exceeds 2^32 ray slots");
+  s->have_rp = false;
+  s->rp = *rp;
+  RenderConst& R = s->rc;
+  R.width = rp->width; R.height = rp->height; R.tiles_x = tx; R.frame = rp->frame;
+  memcpy(R.eye, rp->eye, sizeof R.eye);
+  memcpy(R.cam, rp->camera, sizeof R.cam);
+  R.two_over_w = 2.0 / (double)rp->width;
+  R.two_over_h = 2.0 / (double)rp->height;
+  R.aspect = (double)rp->width / (double)rp->height;
+  s->spp_done = 0;
+  if (npix64 == 0) { s->ps.npix = 0; s->have_rp = true; return JADE_OK; }
+  int rc = setup_state(s, (int)npix64, nslots);
+  if (rc) return rc;
+  HIP_TRY(upload(s->b_tiles, s->tile_ids.data(), s->tile_ids.size()));
+  HIP_TRY(hipMemsetAsync(s->b_ctr.p, 0, sizeof(DevCounters), s->stream));
+  hipLaunchKernelGGL(k_init, dim3((unsigned)((npix64 + 255) / 256)), dim3(256), 0, s->stream, s->ps, s->rc, s->b_tiles.as<int32_t>());
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  s->have_rp = true;
+  return JADE_OK;
+}
+
+// shade/trace passes until a shade pass emits no ray.  The host reads the
+// queue length after every shade pass (that sync is also what lets one event
+// pair time every k_trace launch on this stream).
+static int run_passes(jade_scene* s, uint32_t target_spp, double* ms_out, double* trace_ms_out, uint64_t* launches_out) {
+  const int npix = s->ps.npix;
+  QueueCtl* qc = s->b_ctl.as<QueueCtl>();
+  hipEvent_t ev0, ev1, ta, tb;
+  HIP_TRY(hipEventCreate(&ev0));
+  HIP_TRY(hipEventCreate(&ev1));
+  HIP_TRY(hipEventCreate(&ta));
+  HIP_TRY(hipEventCreate(&tb));
+  HIP_TRY(hipEventRecord(ev0, s->stream));
+  const unsigned shade_blocks = (unsigned)((npix + 255) / 256);
+  bool trace_pending = false;
+  double trace_ms = 0;
+  uint64_t launches = 0;
+  for (;;) {
+    HIP_TRY(hipMemsetAsync(qc, 0, 8, s->stream));  // count, next
+    hipLaunchKernelGGL(k_shade, dim3(shade_blocks), dim3(256), 0, s->stream, s->dev, s->ps, s->rc, s->b_tiles.as<int32_t>(),
+                       target_spp, s->b_queue.as<uint32_t>(), qc, s->b_ctr.as<DevCounters>());
+    uint32_t count = 0;
+    HIP_TRY(hipMemcpyAsync(&count, &qc->count, 4, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (trace_pending) {
+      float t = 0;
+      HIP_TRY(hipEventElapsedTime(&t, ta, tb));
+      trace_ms += t;
+      launches += 1;
+      trace_pending = false;
+    }
+    if (count == 0) break;
+    HIP_TRY(hipEventRecord(ta, s->stream));
+    hipLaunchKernelGGL(k_trace, dim3((unsigned)s->trace_blocks), dim3(JADE_TRACE_BLOCK), 0, s->stream, s->dev, s->ps,
+                       s->b_queue.as<uint32_t>(), qc, s->b_spill.as<uint32_t>(), s->b_ctr.as<DevCounters>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(tb, s->stream));
+    trace_pending = true;
+  }
+  HIP_TRY(hipEventRecord(ev1, s->stream));
+  HIP_TRY(hipEventSynchronize(ev1));
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+  (void)hipEventDestroy(ev0);
+  (void)hipEventDestroy(ev1);
+  (void)hipEventDestroy(ta);
+  (void)hipEventDestroy(tb);
+  *ms_out = ms;
+  *trace_ms_out = trace_ms;
+  *launches_out = launches;
+  return JADE_OK;
+}
+
+int jade_render_step(jade_scene* s, int32_t spp, jade_stats* st) {
+  if (!s || !s->have_rp) return fail(JADE_ERR_INVALID, "jade_render_begin not called");
+  if (spp < 0) return fail(JADE_ERR_INVALID, "negative spp");
+  HIP_TRY(hipSetDevice(s->device));
+  s->spp_done += spp;
+  if (s->ps.npix == 0 || spp == 0) return JADE_OK;
+  HIP_TRY(hipMemsetAsync(s->b_ctr.p, 0, sizeof(DevCounters), s->stream));
+  double ms = 0, trace_ms = 0;
+  uint64_t launches = 0;
+  int rc = run_passes(s, (uint32_t)s->spp_done, &ms, &trace_ms, &launches);
+  if (rc) return rc;
+  if (st) {
+    DevCounters c{};
+    HIP_TRY(hipMemcpy(&c, s->b_ctr.p, sizeof c, hipMemcpyDeviceToHost));
+    st->rays_primary += c.rays_primary;
+    st->rays_secondary += c.rays_secondary;
+    st->nodes_visited += c.nodes_visited;
+    st->tris_tested += c.tris_tested;
+    st->shaded_hits += c.shaded_hits;
+    st->samples += c.samples;
+    st->kernel_ms += ms;
+    st->trace_ms += trace_ms;
+    st->trace_launches += launches;
+  }
+  return JADE_OK;
+}
+
+static int resolve_to(jade_scene* s, float* dev_rgb, uint8_t* dev_bgr, hipStream_t stream) {
+  const int npix = s->ps.npix;
+  if (npix == 0) return JADE_OK;
+  float inv = (float)(1.0 / (double)s->spp_done);  // vec3(1.0 / spp), PathTrace.cu:1457
+  hipLaunchKernelGGL(k_resolve, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream, s->ps, inv, dev_rgb, dev_bgr);
+  HIP_TRY(hipGetLastError());
+  return JADE_OK;
+}
+
+int jade_render_resolve(jade_scene* s, float* out_rgb, uint8_t* out_bgr8) {
+  if (!s || !s->have_rp) return fail(JADE_ERR_INVALID, "jade_render_begin not called");
+  if (s->spp_done <= 0) return fail(JADE_ERR_INVALID, "no samples rendered yet");
+  HIP_TRY(hipSetDevice(s->device));
+  const int npix = s->ps.npix;
+  if (npix == 0) return JADE_OK;
+  if (out_rgb) HIP_TRY(s->b_out_rgb.alloc((size_t)npix * 12));
+  if (out_bgr8) HIP_TRY(s->b_out_bgr.alloc((size_t)npix * 3));
+  int rc = resolve_to(s, out_rgb ? s->b_out_rgb.as<float>() : nullptr, out_bgr8 ? s->b_out_bgr.as<uint8_t>() : nullptr, s->stream);
+  if (rc) return rc;
+  std::vector<float> hrgb;
+  std::vector<uint8_t> hbgr;
+  if (out_rgb) {
+    hrgb.resize((size_t)npix * 3);
+    HIP_TRY(hipMemcpyAsync(hrgb.data(), s->b_out_rgb.p, hrgb.size() * 4, hipMemcpyDeviceToHost, s->stream));
+  }
+  if (out_bgr8) {
+    hbgr.resize((size_t)npix * 3);
+    HIP_TRY(hipMemcpyAsync(hbgr.data(), s->b_out_bgr.p, hbgr.size(), hipMemcpyDeviceToHost, s->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  // scatter the compact tiles into the caller's frame; other ranks' pixels untouched
+  const int W = s->rp.width, H = s->rp.height, tx = s->rc.tiles_x;
+  for (size_t t = 0; t < s->tile_ids.size(); ++t) {
+    int x0 = (s->tile_ids[t] % tx) * JADE_TILE_SIZE, y0 = (s->tile_ids[t] / tx) * JADE_TILE_SIZE;
+    int ww = std::min(JADE_TILE_SIZE, W - x0), hh = std::min(JADE_TILE_SIZE, H - y0);
+    for (int ly = 0; ly < hh; ++ly) {
+      size_t src = (t * 256 + (size_t)ly * 16) * 3, dst = ((size_t)(y0 + ly) * W + x0) * 3;
+      if (out_rgb) memcpy(out_rgb + dst, hrgb.data() + src, (size_t)ww * 12);
+      if (out_bgr8) memcpy(out_bgr8 + dst, hbgr.data() + src, (size_t)ww * 3);
+    }
+  }
+  return JADE_OK;
+}
+
+int jade_render_resolve_tiles_device(jade_scene* s, float* dev_tiles, void* stream) {
+  if (!s || !s->have_rp || !dev_tiles) return fail(JADE_ERR_INVALID, "bad arguments");
+  if (s->spp_done <= 0) return fail(JADE_ERR_INVALID, "no samples rendered yet");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return resolve_to(s, dev_tiles, nullptr, (hipStream_t)stream);
+}
+
+int jade_render(jade_scene* s, const jade_render_params* rp, float* out_rgb, uint8_t* out_bgr8, jade_stats* st) {
+  if (!rp) return fail(JADE_ERR_INVALID, "null argument");
+  if (rp->spp <= 0) return fail(JADE_ERR_INVALID, "spp must be positive");
+  int rc = jade_render_begin(s, rp);
+  if (rc) return rc;
+  rc = jade_render_step(s, rp->spp, st);
+  if (rc) return rc;
+  return jade_render_resolve(s, out_rgb, out_bgr8);
+}
+
+int jade_trace_rays(jade_scene* s, int32_t n, const float* origins, const float* dirs, const int32_t* skip, int32_t* hit_index,
+                    float* hit_dist, float* hit_point, jade_stats* st) {
+  if (!s || n < 0 || !origins || !dirs || !skip || !hit_index) return fail(JADE_ERR_INVALID, "null argument");
+  if (n == 0) return JADE_OK;
+  HIP_TRY(hipSetDevice(s->device));
+  // a throw-away PathState with one slot per "pixel"
+  const size_t N = (size_t)n;
+  std::vector<float> so(3 * N), sd(3 * N);
+  for (size_t i = 0; i < N; ++i)
+    for (int c = 0; c < 3; ++c) { so[c * N + i] = origins[3 * i + c]; sd[c * N + i] = dirs[3 * i + c]; }
+  std::vector<uint32_t> q(N);
+  for (size_t i = 0; i < N; ++i) q[i] = (uint32_t)i;
+  DevBuf b_org, b_dir, b_skip, b_hit, b_hpt, b_q, b_spill;
+  HIP_TRY(upload(b_org, so.data(), so.size()));
+  HIP_TRY(upload(b_dir, sd.data(), sd.size()));
+  HIP_TRY(upload(b_skip, skip, N));
+  HIP_TRY(b_hit.alloc(N * 4));
+  HIP_TRY(b_hpt.alloc(3 * N * 4));
+  HIP_TRY(upload(b_q, q.data(), N));
+  HIP_TRY(b_spill.alloc((size_t)(JADE_BVH_STACK_CAPACITY - JADE_LDS_STACK) * s->trace_blocks * JADE_TRACE_BLOCK * 4));
+  PathState P{};
+  P.npix = n;
+  P.nslots = 1;
+  P.org = b_org.as<float>(); P.dir = b_dir.as<float>(); P.skip = b_skip.as<int32_t>();
+  P.hit = b_hit.as<int32_t>(); P.hpt = b_hpt.as<float>();
+  QueueCtl qc{};
+  qc.count = (uint32_t)n;
+  HIP_TRY(hipMemcpy(s->b_ctl.p, &qc, 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(s->b_ctr.p, 0, sizeof(DevCounters)));
+  hipEvent_t ev0, ev1;
+  HIP_TRY(hipEventCreate(&ev0));
+  HIP_TRY(hipEventCreate(&ev1));
+  HIP_TRY(hipEventRecord(ev0, s->stream));
+  hipLaunchKernelGGL(k_trace, dim3((unsigned)s->trace_blocks), dim3(JADE_TRACE_BLOCK), 0, s->stream, s->dev, P, b_q.as<uint32_t>(),
+                     s->b_ctl.as<QueueCtl>(), b_spill.as<uint32_t>(), s->b_ctr.as<DevCounters>());
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(ev1, s->stream));
+  HIP_TRY(hipEventSynchronize(ev1));
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+  (void)hipEventDestroy(ev0);
+  (void)hipEventDestroy(ev1);
+  std::vector<float> hp(3 * N);
+  HIP_TRY(hipMemcpy(hit_index, b_hit.p, N * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(hp.data(), b_hpt.p, 3 * N * 4, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < N; ++i) {
+    float px = hp[i], py = hp[N + i], pz = hp[2 * N + i];
+    if (hit_point) { hit_point[3 * i] = px; hit_point[3 * i + 1] = py; hit_point[3 * i + 2] = pz; }
+    if (hit_dist) {
+      // HitResult.distance = dot(P - o, normalize(d)), PathTrace.cu:740; recomputed with the shared helpers
+      if (hit_index[i] < 0) hit_dist[i] = JADE_INF_F;
+      else {
+        jvec3 o = jv(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]);
+        jvec3 dn = jv_normalize(jv(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]));
+        hit_dist[i] = jv_dot(jv_sub(jv(px, py, pz), o), dn);
+      }
+    }
+  }
+  if (st) {
+    DevCounters c{};
+    HIP_TRY(hipMemcpy(&c, s->b_ctr.p, sizeof c, hipMemcpyDeviceToHost));
+    st->rays_secondary += (uint64_t)n;
+    st->nodes_visited += c.nodes_visited;
+    st->tris_tested += c.tris_tested;
+    st->kernel_ms += ms;
+    st->trace_ms += ms;
+    st->trace_launches += 1;
+  }
+  return JADE_OK;
+}
+
+}  // extern "C"

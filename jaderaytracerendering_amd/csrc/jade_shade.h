@@ -1,0 +1,534 @@
+// jade_shade.h — the bounce loop of pathTracing (PathTrace.cu:905-1416) and the
+// sample loop of render_pixel (:1418-1455) as a per-pixel state machine.
+//
+// The reference runs one thread per pixel through `spp` samples and calls
+// hitBVH inline (nEmit + 2 times per bounce).  Here a pixel is a record in
+// HBM; each pass of k_shade (a) folds the hit results of the rays it issued on
+// the previous pass into the path, (b) samples the next bounce and (c) emits
+// ALL rays of that bounce at once into a compacted queue for k_trace.  That is
+// possible because no random draw of a bounce depends on a hit result of the
+// same bounce: the draw order below is the textual order of the
+// curand_uniform calls, only the hitBVH calls are deferred.
+//
+// Radiance bookkeeping: the reference pushes (dir, rate) pairs on two
+// 128-entry stacks and unwinds them Horner-style (:1410-1413).  The same sum
+// is accumulated forward here (acc += thr * dir; thr *= rate), which differs
+// from the unwind only by fp32 rounding of the radiance (never of a decision).
+#pragma once
+#include "jade_device.h"
+
+static __device__ __forceinline__ int mirror_index(int i, int n) {
+  int m = i % (2 * n);
+  if (m < 0) m += 2 * n;
+  if (m >= n) m = 2 * n - 1 - m;
+  return m;
+}
+
+// sampleHdr / SampleSphericalMap, PathTrace.cu:686-702; software bilinear with
+// mirror addressing in place of tex2D (gfx950 has no sampler path).
+static __device__ jvec3 sample_hdr(const DevScene& S, jvec3 v) {
+  jvec3 nv = jv_normalize(v);
+  float ux = jade_atan2f(nv.z, nv.x);
+  float uy = jade_asinf(nv.y);
+  ux = (float)((double)ux / (2.0 * JADE_PI_D));
+  uy = (float)((double)uy / JADE_PI_D);
+  ux = (float)((double)ux + 0.5);
+  uy = (float)((double)uy + 0.5);
+  uy = (float)(1.0 - (double)uy);
+  const int W = S.env_w, H = S.env_h;
+  if (jade_isnan(ux)) ux = 0.0f;
+  if (jade_isnan(uy)) uy = 0.0f;
+  float x = ux * (float)W - 0.5f;
+  float y = uy * (float)H - 0.5f;
+  float xf = jade_floorf(x), yf = jade_floorf(y);
+  float ax = x - xf, ay = y - yf;
+  int i0 = mirror_index((int)xf, W), i1 = mirror_index((int)xf + 1, W);
+  int j0 = mirror_index((int)yf, H), j1 = mirror_index((int)yf + 1, H);
+  float w00 = (1.0f - ax) * (1.0f - ay), w10 = ax * (1.0f - ay);
+  float w01 = (1.0f - ax) * ay, w11 = ax * ay;
+  const float* t00 = S.env + 3 * ((size_t)j0 * W + i0);
+  const float* t10 = S.env + 3 * ((size_t)j0 * W + i1);
+  const float* t01 = S.env + 3 * ((size_t)j1 * W + i0);
+  const float* t11 = S.env + 3 * ((size_t)j1 * W + i1);
+  jvec3 c;
+  c.x = ((w00 * t00[0] + w10 * t10[0]) + w01 * t01[0]) + w11 * t11[0];
+  c.y = ((w00 * t00[1] + w10 * t10[1]) + w01 * t01[1]) + w11 * t11[1];
+  c.z = ((w00 * t00[2] + w10 * t10[2]) + w01 * t01[2]) + w11 * t11[2];
+  c.x = c.x < 10.0f ? c.x : 10.0f;
+  c.y = c.y < 10.0f ? c.y : 10.0f;
+  c.z = c.z < 10.0f ? c.z : 10.0f;
+  return c;
+}
+
+static __device__ __forceinline__ jvec3 sphere_dir(uint32_t* rng) {  // PathTrace.cu:968-971
+  float cosine_theta = (float)(2.0 * ((double)jade_rand(rng) - 0.5));
+  float sine_theta = jade_sqrt(1.0f - cosine_theta * cosine_theta);
+  float fai_value = (float)(2.0 * JADE_PI_D * (double)jade_rand(rng));
+  float sn, cs;
+  jade_sincosf(fai_value, &sn, &cs);
+  return jv(sine_theta * cs, sine_theta * sn, cosine_theta);
+}
+
+static __device__ __forceinline__ jvec3 tri_point(const jade_triangle* t, float rx, float ry) {
+  jvec3 p1 = V3(t->p1);
+  return jv_add(jv_add(p1, jv_scale(jv_sub(V3(t->p2), p1), rx)), jv_scale(jv_sub(V3(t->p3), p1), ry));
+}
+
+static __device__ __forceinline__ float tri_size(const jade_triangle* t) {  // PathTrace.cu:897-903
+  jvec3 cp = jv_cross(jv_sub(V3(t->p2), V3(t->p1)), jv_sub(V3(t->p3), V3(t->p1)));
+  return 0.5f * jade_sqrt(jv_dot(cp, cp));
+}
+
+static __device__ __forceinline__ bool nonemissive(const jade_triangle* t) {
+  return t->emissive[0] < 1.5e-4f && t->emissive[1] < 1.5e-4f && t->emissive[2] < 1.5e-4f;
+}
+
+static __device__ __forceinline__ float schlick_out(float R0, float cosine_abs) {  // "R0 - (1-R0)(...)^5", :1102
+  float one_cosine_o = 1 - cosine_abs;
+  float one_cosine_o_sqr = one_cosine_o * one_cosine_o;
+  return R0 - (1 - R0) * one_cosine_o_sqr * one_cosine_o_sqr * one_cosine_o;
+}
+
+// gen_refract_ray, PathTrace.cu:876-894
+static __device__ jvec3 gen_refract_ray(jvec3 direction_in, jvec3 normal_line, float eta, bool* full_reflex) {
+  float cosi = jv_dot(direction_in, normal_line);
+  if (cosi > 0) normal_line = jv_neg(normal_line);
+  else cosi *= -1;
+  float cost2 = 1.0f - eta * eta * (1.0f - cosi * cosi);
+  if (cost2 > 0) {
+    *full_reflex = false;
+    return jv_add(jv_scale(direction_in, eta), jv_scale(normal_line, eta * cosi - jade_sqrt(cost2)));
+  }
+  *full_reflex = true;
+  return direction_in;
+}
+
+// One lane's view of its pixel record.
+struct Px {
+  const PathState& P;
+  int p;
+  __device__ Px(const PathState& ps, int pix) : P(ps), p(pix) {}
+  __device__ jvec3 dir(int k) const {
+    const float* b = P.dir + (size_t)k * P.npix;
+    const size_t pl = (size_t)P.nslots * P.npix;
+    return jv(b[p], b[pl + p], b[2 * pl + p]);
+  }
+  __device__ void set_dir(int k, jvec3 v) const {
+    float* b = P.dir + (size_t)k * P.npix;
+    const size_t pl = (size_t)P.nslots * P.npix;
+    b[p] = v.x; b[pl + p] = v.y; b[2 * pl + p] = v.z;
+  }
+  __device__ jvec3 hpt(int k) const {
+    const float* b = P.hpt + (size_t)k * P.npix;
+    const size_t pl = (size_t)P.nslots * P.npix;
+    return jv(b[p], b[pl + p], b[2 * pl + p]);
+  }
+  __device__ int hit(int k) const { return P.hit[(size_t)k * P.npix + p]; }
+  __device__ void set_hit(int k, int v) const { P.hit[(size_t)k * P.npix + p] = v; }
+};
+
+struct ShadeCtx {
+  uint32_t rng;
+  uint32_t stage, depth, flags;
+  jvec3 thr, acc, le;
+  int32_t obj;
+  jvec3 src, out;
+  // what this pass emits
+  int n_emit_rays;  // number of active slots written
+  // counters
+  uint32_t c_primary, c_secondary, c_shaded, c_samples;
+};
+
+// push (dir, rate) — forward form of stack_dir / stack_indir_rate.  Returns
+// true when the reference's `while (stack_offset < STACK_CAPACITY)` would stop.
+static __device__ __forceinline__ bool path_push(ShadeCtx& c, jvec3 dirv, jvec3 rate) {
+  c.acc = jv_add(c.acc, jv_mul(c.thr, dirv));
+  c.thr = jv_mul(c.thr, rate);
+  c.depth += 1;
+  return c.depth >= JADE_STACK_CAPACITY;
+}
+
+// Sample the bounce at the current vertex and emit its rays.  Returns false
+// if the path ended at this vertex (l_final holds the last l_dir).
+static __device__ bool begin_bounce(const DevScene& S, const Px& px, ShadeCtx& c, jvec3* l_final) {
+  const jade_triangle* T = S.tris;
+  const jade_triangle* ot = &T[c.obj];
+  const int nE = S.n_emit;
+  const float RR_F = (float)JADE_RR_RATE_D;
+  c.c_shaded += 1;
+  jvec3 obj_emissive = V3(ot->emissive);
+  if (obj_emissive.x > 1.4e-5f || obj_emissive.y > 1.4e-5f || obj_emissive.z > 1.4e-5f) {
+    *l_final = obj_emissive;  // PathTrace.cu:916-920
+    return false;
+  }
+  *l_final = jv(0, 0, 0);
+  const jvec3 n = V3(ot->norm);
+  float select_reflex_refract = jade_rand(&c.rng);
+  const int pix = px.p;
+  const int npix = px.P.npix;
+  if (select_reflex_refract < 0.5f && ot->refract_mode != JADE_NO_REFRACT) {
+    if (ot->refract_mode == JADE_SUB_SURFACE) {
+      select_reflex_refract = jade_rand(&c.rng);
+      if (select_reflex_refract < (float)JADE_SSS_RATE_D) {
+        c.stage = ST_DIFFUSE;
+        c.flags = STF_SSS;
+        goto diffuse_like;
+      }
+      // ---- BSSRDF, PathTrace.cu:1029-1178 ----
+      const jade_obj_seg seg = S.segs[ot->obj_idx];
+      float random_idx = jade_rand(&c.rng) * S.prefix[seg.end_idx];
+      int left = seg.begin_idx, right = seg.end_idx, middle = 0;
+      while (left < right - 1) {
+        middle = (left + right) / 2;
+        float pm = S.prefix[middle];
+        if (random_idx <= pm) right = middle;
+        else if (random_idx >= pm) left = middle;
+        else break;
+      }
+      middle = S.mapping[middle];
+      float rand_x = jade_rand(&c.rng);
+      float rand_y = jade_rand(&c.rng);
+      if (rand_x + rand_y > 1) {
+        rand_x = 1 - rand_x;
+        rand_y = 1 - rand_y;
+      }
+      const jade_triangle* t_i = &T[middle];
+      const jvec3 t_norm = V3(t_i->norm);
+      const jvec3 rate = V3(t_i->refract_rate);
+      jvec3 random_point = tri_point(t_i, rand_x, rand_y);
+      jvec3 inner_direction = jv_sub(random_point, c.src);
+      float inner_distance = jade_sqrt(jv_dot(inner_direction, inner_direction));
+      float neg_d = -1.0f * inner_distance;
+      float neg_d3 = (float)((double)neg_d / 3.0);
+      const float E_F = (float)JADE_E_D;
+      jvec3 e1 = jv(jade_powf(E_F, neg_d / rate.x), jade_powf(E_F, neg_d / rate.y), jade_powf(E_F, neg_d / rate.z));
+      jvec3 e2 = jv(jade_powf(E_F, neg_d3 / rate.x), jade_powf(E_F, neg_d3 / rate.y), jade_powf(E_F, neg_d3 / rate.z));
+      jvec3 bssrdf = jv_div(jv_add(e1, e2), jv_scale(rate, (float)(8 * JADE_PI_D * (double)inner_distance)));
+      float eta = t_i->refract_index;
+      float R0 = (eta - 1) / (eta + 1) * (eta - 1) / (eta + 1);
+      float one_cosine_i = 1 - jade_fabs(jv_dot(n, c.out));
+      float one_cosine_i_sqr = one_cosine_i * one_cosine_i;
+      float fresnel_rate_i = R0 + (1 - R0) * one_cosine_i_sqr * one_cosine_i_sqr * one_cosine_i;
+      bssrdf = jv_scale(bssrdf, fresnel_rate_i);
+
+      st3(px.P.org, npix, pix, random_point);
+      px.P.skip[pix] = middle;
+      st3(px.P.aux, npix, pix, bssrdf);
+      for (int i = 0; i < nE; ++i) {
+        float rx = jade_rand(&c.rng);
+        float ry = jade_rand(&c.rng);
+        if (rx + ry > 1) {
+          rx = 1 - rx;
+          ry = 1 - ry;
+        }
+        jvec3 random_emit_point = tri_point(&T[S.emit[i]], rx, ry);
+        px.set_dir(i, jv_sub(random_emit_point, random_point));
+        px.set_hit(i, -1);
+        c.n_emit_rays++;
+      }
+      {
+        jvec3 ray_direction = sphere_dir(&c.rng);
+        if (jv_dot(ray_direction, t_norm) * jv_dot(inner_direction, t_norm) < 0) ray_direction = jv_neg(ray_direction);
+        px.set_dir(nE, ray_direction);
+        px.set_hit(nE, -1);
+        c.n_emit_rays++;
+      }
+      jvec3 ray_direction = sphere_dir(&c.rng);
+      if (jv_dot(ray_direction, t_norm) * jv_dot(inner_direction, t_norm) > 0) ray_direction = jv_neg(ray_direction);
+      float rr_result = jade_rand(&c.rng);
+      c.stage = ST_BSSRDF;
+      c.flags = 0;
+      if (rr_result < RR_F) {
+        c.flags = STF_RR;
+        px.set_dir(nE + 1, ray_direction);
+        px.set_hit(nE + 1, -1);
+        c.n_emit_rays++;
+      } else {
+        px.set_hit(nE + 1, -2);
+      }
+      return true;
+    }
+    // ---- direct refraction entry, PathTrace.cu:1180-1199 ----
+    {
+      float triangle_miu = ot->refract_index;
+      float R0 = (1 - triangle_miu) / (1 + triangle_miu) * (1 - triangle_miu) / (1 + triangle_miu);
+      float one_cosine_i = 1 - jade_fabs(jv_dot(n, c.out));
+      float one_cosine_i_sqr = one_cosine_i * one_cosine_i;
+      float fresnel_rate_i = R0 + (1 - R0) * one_cosine_i_sqr * one_cosine_i_sqr * one_cosine_i;
+      bool full_reflex = false;
+      jvec3 rev_out_direction = jv_scale(c.out, -1.0f);
+      jvec3 refract_ray = gen_refract_ray(rev_out_direction, n, (float)(1.0 / (double)triangle_miu), &full_reflex);
+      st3(px.P.aux, npix, pix, jv(1 - fresnel_rate_i, 1 - fresnel_rate_i, 1 - fresnel_rate_i));
+      px.P.auxi[pix] = 0;
+      st3(px.P.org, npix, pix, c.src);
+      px.P.skip[pix] = c.obj;
+      px.set_dir(0, refract_ray);
+      px.set_hit(0, -1);
+      c.n_emit_rays++;
+      c.stage = ST_REFRACT_LOOP;
+      c.flags = 0;
+      return true;
+    }
+  }
+  if (ot->reflex_mode == JADE_DIFFUSE) {
+    c.stage = ST_DIFFUSE;
+    c.flags = 0;
+    goto diffuse_like;
+  }
+  // ---- mirror, PathTrace.cu:1365-1405 ----
+  {
+    jvec3 obj_hit_fr = jv_scale(V3(ot->brdf), (float)(1.0 / JADE_PI_D));
+    int k = ot->refract_mode != JADE_NO_REFRACT ? 2 : 1;
+    if (obj_emissive.x > 1.5e-4f || obj_emissive.y > 1.5e-4f || obj_emissive.x > 1.5e-4f) {
+      *l_final = jv_scale(jv_mul(obj_emissive, obj_hit_fr), (float)k);
+      return false;
+    }
+    float rr_result = jade_rand(&c.rng);
+    if (!(rr_result < RR_F)) return false;
+    jvec3 refl = jv_sub(jv_scale(n, 2 * jv_dot(c.out, n)), c.out);
+    st3(px.P.org, npix, pix, c.src);
+    px.P.skip[pix] = c.obj;
+    px.set_dir(0, refl);
+    px.set_hit(0, -1);
+    c.n_emit_rays++;
+    c.stage = ST_MIRROR;
+    c.flags = 0;
+    return true;
+  }
+
+diffuse_like:
+  // ---- diffuse (:1266-1364) and SSS-diffuse (:931-1028): same ray set ----
+  {
+    st3(px.P.org, npix, pix, c.src);
+    px.P.skip[pix] = c.obj;
+    const float side = jv_dot(c.out, n);
+    for (int i = 0; i < nE; ++i) {
+      float rand_x = jade_rand(&c.rng);
+      float rand_y = jade_rand(&c.rng);
+      if (rand_x + rand_y > 1) {
+        rand_x = 1 - rand_x;
+        rand_y = 1 - rand_y;
+      }
+      jvec3 random_point = tri_point(&T[S.emit[i]], rand_x, rand_y);
+      jvec3 obj_light_direction = jv_sub(random_point, c.src);
+      px.set_dir(i, obj_light_direction);
+      if (jv_dot(obj_light_direction, n) * side < 0) {
+        px.set_hit(i, -2);  // `continue`: no shadow ray
+      } else {
+        px.set_hit(i, -1);
+        c.n_emit_rays++;
+      }
+    }
+    {
+      jvec3 ray_direction = sphere_dir(&c.rng);
+      if (jv_dot(ray_direction, n) * side < 0) ray_direction = jv_neg(ray_direction);
+      px.set_dir(nE, ray_direction);
+      px.set_hit(nE, -1);
+      c.n_emit_rays++;
+    }
+    float rr_result = jade_rand(&c.rng);
+    if (rr_result < RR_F) {
+      jvec3 ray_direction = sphere_dir(&c.rng);
+      if (jv_dot(ray_direction, n) * side < 0) ray_direction = jv_neg(ray_direction);
+      c.flags |= STF_RR;
+      px.set_dir(nE + 1, ray_direction);
+      px.set_hit(nE + 1, -1);
+      c.n_emit_rays++;
+    } else {
+      px.set_hit(nE + 1, -2);
+    }
+    return true;
+  }
+}
+
+// Outcome of folding the pending rays' results into the path.
+enum { CONSUME_VERTEX = 0, CONSUME_END = 1, CONSUME_ZERO = 2, CONSUME_EMITTED = 3 };
+
+// Fold the results of the rays issued last pass.  CONSUME_VERTEX: the path
+// moved to a new vertex (c.obj/src/out updated); CONSUME_END: it ended with
+// *l_final; CONSUME_ZERO: pathTracing returned 0 (:1231); CONSUME_EMITTED: the
+// refraction loop issued its next ray.
+static __device__ int consume(const DevScene& S, const Px& px, ShadeCtx& c, jvec3* l_final) {
+  const jade_triangle* T = S.tris;
+  const int nE = S.n_emit;
+  const float PI_F = (float)JADE_PI_D;
+  const float RR_F = (float)JADE_RR_RATE_D;
+  const int pix = px.p, npix = px.P.npix;
+  const jade_triangle* ot = &T[c.obj];
+  const jvec3 n = V3(ot->norm);
+  const int k = ot->refract_mode != JADE_NO_REFRACT ? 2 : 1;
+  const jvec3 obj_hit_fr = jv_scale(V3(ot->brdf), (float)(1.0 / JADE_PI_D));
+  jvec3 l_dir = jv(0, 0, 0);
+
+  if (c.stage == ST_DIFFUSE) {
+    const bool sss = (c.flags & STF_SSS) != 0;
+    const jvec3 f = sss ? jv_scale(V3(ot->refract_albedo), (float)(1.0 / JADE_PI_D)) : obj_hit_fr;
+    for (int i = 0; i < nE; ++i) {
+      int h = px.hit(i);
+      int emit_tri_idx = S.emit[i];
+      if (h >= 0 && h == emit_tri_idx) {
+        jvec3 ld = px.dir(i);
+        const jade_triangle* t_i = &T[emit_tri_idx];
+        float dls = jv_dot(ld, ld);
+        jvec3 w = jv_mul(V3(t_i->emissive), f);
+        w = jv_scale(w, jade_fabs(jv_dot(n, ld) * jv_dot(V3(t_i->norm), ld)));
+        w = jv_divs(jv_divs(w, dls), dls);
+        w = jv_scale(w, tri_size(t_i));
+        l_dir = jv_add(l_dir, w);
+      }
+    }
+    if (px.hit(nE) < 0) {
+      jvec3 rd = px.dir(nE);
+      jvec3 w = jv_mul(sample_hdr(S, rd), f);
+      w = jv_scale(w, jade_fabs(jv_dot(n, rd)));
+      w = jv_scale(jv_scale(w, 2.0f), PI_F);
+      l_dir = jv_add(l_dir, w);
+    }
+    l_dir = jv_scale(l_dir, sss ? (float)(k / JADE_SSS_RATE_D) : (float)k);
+    *l_final = l_dir;
+    if (!(c.flags & STF_RR)) return CONSUME_END;
+    int nh = px.hit(nE + 1);
+    if (nh >= 0 && nonemissive(&T[nh])) {
+      jvec3 rd = jv_neg(px.dir(nE + 1));
+      jvec3 indir_rate = jv_divs(jv_scale(obj_hit_fr, jade_fabs(jv_dot(rd, n))), RR_F);
+      jvec3 rate = sss ? jv_divs(jv_scale(indir_rate, (float)k), (float)JADE_SSS_RATE_D) : jv_scale(indir_rate, (float)k);
+      c.src = px.hpt(nE + 1);
+      c.out = rd;
+      c.obj = nh;
+      return path_push(c, l_dir, rate) ? CONSUME_END : CONSUME_VERTEX;
+    }
+    return CONSUME_END;
+  }
+
+  if (c.stage == ST_BSSRDF) {
+    const int middle = px.P.skip[pix];
+    const jade_triangle* t_i = &T[middle];
+    const jvec3 t_norm = V3(t_i->norm);
+    const jvec3 bssrdf = ld3(px.P.aux, npix, pix);
+    const float eta = t_i->refract_index;
+    const float R0 = (eta - 1) / (eta + 1) * (eta - 1) / (eta + 1);
+    const float area_total = S.prefix[S.segs[t_i->obj_idx].end_idx];
+    for (int i = 0; i < nE; ++i) {
+      int h = px.hit(i);
+      int emit_tri_idx = S.emit[i];
+      if (h >= 0 && h == emit_tri_idx) {
+        jvec3 ld = px.dir(i);
+        const jade_triangle* emit_i = &T[emit_tri_idx];
+        float fresnel_rate_o = schlick_out(R0, jade_fabs(jv_dot(jv_normalize(ld), t_norm)));
+        float dls = jv_dot(ld, ld);
+        jvec3 w = jv_scale(V3(emit_i->emissive), fresnel_rate_o);
+        w = jv_mul(w, bssrdf);
+        w = jv_scale(w, jade_fabs(jv_dot(t_norm, ld) * jv_dot(V3(emit_i->norm), ld)));
+        w = jv_divs(jv_divs(w, dls), dls);
+        w = jv_scale(w, tri_size(emit_i));
+        w = jv_divs(w, PI_F);
+        w = jv_scale(w, area_total);
+        l_dir = jv_add(l_dir, w);
+      }
+    }
+    if (px.hit(nE) < 0) {
+      jvec3 rd = px.dir(nE);
+      float fresnel_rate_o = schlick_out(R0, jade_fabs(jv_dot(rd, t_norm)));
+      jvec3 w = jv_mul(jv_scale(sample_hdr(S, rd), fresnel_rate_o), bssrdf);
+      w = jv_scale(jv_scale(w, jade_fabs(jv_dot(t_norm, rd))), 2.0f);
+      l_dir = jv_add(l_dir, w);
+    }
+    l_dir = jv_scale(l_dir, (float)(k / (1 - JADE_SSS_RATE_D)));
+    *l_final = l_dir;
+    if (!(c.flags & STF_RR)) return CONSUME_END;
+    int nh = px.hit(nE + 1);
+    if (nh >= 0 && nonemissive(&T[nh])) {
+      jvec3 rd = jv_neg(px.dir(nE + 1));
+      float fresnel_rate_o = schlick_out(R0, jade_fabs(jv_dot(rd, t_norm)));
+      jvec3 indir_rate = jv_scale(bssrdf, fresnel_rate_o);
+      indir_rate = jv_scale(indir_rate, jade_fabs(jv_dot(rd, t_norm)));
+      indir_rate = jv_scale(indir_rate, area_total);
+      indir_rate = jv_divs(jv_scale(indir_rate, 2.0f), RR_F);
+      jvec3 rate = jv_divs(jv_scale(indir_rate, (float)k), (float)(1 - JADE_SSS_RATE_D));
+      c.src = px.hpt(nE + 1);
+      c.out = rd;
+      c.obj = nh;
+      return path_push(c, l_dir, rate) ? CONSUME_END : CONSUME_VERTEX;
+    }
+    return CONSUME_END;
+  }
+
+  if (c.stage == ST_MIRROR) {
+    float kk = (float)(k / (JADE_RR_RATE_D / JADE_PI_D));
+    jvec3 refl = px.dir(0);
+    int nh = px.hit(0);
+    if (nh >= 0) {
+      c.out = jv_neg(refl);
+      c.src = px.hpt(0);
+      c.obj = nh;
+      *l_final = jv(0, 0, 0);
+      return path_push(c, jv(0, 0, 0), jv_scale(obj_hit_fr, kk)) ? CONSUME_END : CONSUME_VERTEX;
+    }
+    *l_final = jv_scale(jv_mul(sample_hdr(S, refl), obj_hit_fr), kk);
+    return CONSUME_END;
+  }
+
+  if (c.stage == ST_REFRACT_LOOP) {
+    // one iteration of the for loop at PathTrace.cu:1201-1234
+    const float triangle_miu = ot->refract_index;
+    const float R0 = (1 - triangle_miu) / (1 + triangle_miu) * (1 - triangle_miu) / (1 + triangle_miu);
+    int nh = px.hit(0);
+    if (nh < 0) return CONSUME_ZERO;  // "obj surface is not close": return vec3(0)
+    const jade_triangle* ht = &T[nh];
+    const jvec3 hn = V3(ht->norm);
+    jvec3 refract_ray = px.dir(0);
+    jvec3 start = ld3(px.P.org, npix, pix);
+    jvec3 hp = px.hpt(0);
+    jvec3 l_indir_rate = ld3(px.P.aux, npix, pix);
+    bool full_reflex = false;
+    refract_ray = gen_refract_ray(refract_ray, hn, triangle_miu, &full_reflex);
+    jvec3 distance = jv_sub(start, hp);
+    float dist = jade_sqrt(jv_dot(distance, distance));
+    l_indir_rate = jv_mul(l_indir_rate, jv(jade_powf(ht->refract_rate[0], dist), jade_powf(ht->refract_rate[1], dist),
+                                           jade_powf(ht->refract_rate[2], dist)));
+    float fresnel_rate_o = schlick_out(R0, jade_fabs(jv_dot(refract_ray, hn)));
+    float reflex_refract_select = jade_rand(&c.rng);
+    int it = px.P.auxi[pix] + 1;
+    bool leave = true;
+    if (full_reflex || reflex_refract_select < 0.2f) {
+      refract_ray = jv_sub(refract_ray, jv_scale(hn, 2 * jv_dot(refract_ray, hn)));
+      if (!full_reflex) l_indir_rate = jv_scale(l_indir_rate, fresnel_rate_o * 5);
+      leave = it >= JADE_MAX_FULL_REFLEX_TIME;  // loop exhausted: fall through to the RR test
+    } else {
+      l_indir_rate = jv_scale(l_indir_rate, (float)((1.0 - (double)fresnel_rate_o) * 1.25));
+    }
+    st3(px.P.org, npix, pix, hp);
+    px.P.skip[pix] = nh;
+    st3(px.P.aux, npix, pix, l_indir_rate);
+    px.P.auxi[pix] = it;
+    px.set_dir(0, refract_ray);
+    px.set_hit(0, -1);
+    *l_final = jv(0, 0, 0);
+    if (!leave) {
+      c.n_emit_rays++;
+      return CONSUME_EMITTED;
+    }
+    float rr_result = jade_rand(&c.rng);
+    if (!(rr_result < RR_F)) return CONSUME_END;
+    c.stage = ST_REFRACT_EXIT;
+    c.n_emit_rays++;
+    return CONSUME_EMITTED;
+  }
+
+  // ST_REFRACT_EXIT, PathTrace.cu:1239-1257
+  {
+    jvec3 refract_ray = px.dir(0);
+    jvec3 l_indir_rate = ld3(px.P.aux, npix, pix);
+    float kk = (float)(k / JADE_RR_RATE_D);
+    int nh = px.hit(0);
+    if (nh >= 0) {
+      c.out = jv_scale(refract_ray, -1.0f);
+      c.src = px.hpt(0);
+      c.obj = nh;
+      *l_final = jv(0, 0, 0);
+      return path_push(c, jv(0, 0, 0), jv_scale(l_indir_rate, kk)) ? CONSUME_END : CONSUME_VERTEX;
+    }
+    *l_final = jv_scale(jv_mul(sample_hdr(S, refract_ray), l_indir_rate), kk);
+    return CONSUME_END;
+  }
+}

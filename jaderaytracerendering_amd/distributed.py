@@ -1,0 +1,74 @@
+"""Image-tile data parallelism: one process per GPU, one gather of the framebuffer.
+
+The reference is single-GPU (one `render_pixel` launch, PathTrace.cu:1731).
+Pixels share nothing but the read-only scene and every pixel owns its RNG
+stream, so the image splits into the reference's 16x16 tiles
+(TILE_SIZE, PathTrace.cu:32): rank r renders the tiles whose row-major id is
+congruent to r modulo the world size (interleaved, because cost concentrates
+on the statue).  There is no data-path collective while rendering; the only
+exchange is ONE gather of each rank's compact tile buffer to rank 0
+(`torch.distributed.gather`: RCCL over xGMI with backend "nccl", gloo on CPU).
+"""
+import numpy as np
+
+from . import _abi
+
+TILE = _abi.TILE_SIZE
+TILE_FLOATS = TILE * TILE * 3
+
+
+def tile_grid(width, height):
+    return (width + TILE - 1) // TILE, (height + TILE - 1) // TILE
+
+
+def owned_tile_ids(width, height, rank, nranks):
+    tx, ty = tile_grid(width, height)
+    return np.arange(rank, tx * ty, nranks, dtype=np.int64)
+
+
+def max_owned(width, height, nranks):
+    tx, ty = tile_grid(width, height)
+    return (tx * ty + nranks - 1) // nranks
+
+
+def pack_tiles(image, rank, nranks):
+    """[H, W, 3] full frame -> this rank's compact [n_owned, 16, 16, 3] buffer (zeros outside the image)."""
+    h, w = image.shape[:2]
+    ids = owned_tile_ids(w, h, rank, nranks)
+    tx, _ = tile_grid(w, h)
+    out = np.zeros((len(ids), TILE, TILE, 3), image.dtype)
+    for k, tid in enumerate(ids):
+        y0, x0 = (tid // tx) * TILE, (tid % tx) * TILE
+        hh, ww = min(TILE, h - y0), min(TILE, w - x0)
+        out[k, :hh, :ww] = image[y0:y0 + hh, x0:x0 + ww]
+    return out
+
+
+def gather_framebuffer(tiles, width, height, dst=0, group=None):
+    """Gather every rank's tile buffer on `dst` and assemble the full frame there.
+
+    tiles: torch tensor [n_owned, 16, 16, 3] (CPU for gloo, CUDA for nccl/RCCL).
+    Returns the [height, width, 3] tensor on `dst`, None elsewhere.  Ranks own
+    different tile counts when the tile total is not a multiple of the world
+    size, so buffers are padded to the maximum before the single gather.
+    """
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n_max = max_owned(width, height, world)
+    buf = torch.zeros((n_max, TILE, TILE, 3), dtype=tiles.dtype, device=tiles.device)
+    buf[: tiles.shape[0]] = tiles
+    if world == 1:
+        parts = [buf]
+    else:
+        parts = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
+        dist.gather(buf, parts, dst=dst, group=group)
+    if rank != dst:
+        return None
+    tx, ty = tile_grid(width, height)
+    # tile id t lives at parts[t % world][t // world]; lay tiles out in id order, then un-tile
+    stacked = torch.stack(parts, dim=1).reshape(n_max * world, TILE, TILE, 3)[: tx * ty]
+    frame = stacked.reshape(ty, tx, TILE, TILE, 3).permute(0, 2, 1, 3, 4).reshape(ty * TILE, tx * TILE, 3)
+    return frame[:height, :width].contiguous()

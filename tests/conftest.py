@@ -1,0 +1,73 @@
+"""Shared fixtures.
+
+Roles, fixed by the task's oracle rule:
+  * `oracle`  - oracle/libjade_oracle.so, the CPU restatement of PathTrace.cu:669-1474.
+                It is the CHECKER; nothing under jaderaytracerendering_amd/ imports it.
+  * `hip`     - jaderaytracerendering_amd/lib/libjade_hip.so, the product.  GPU tests
+                call it through the jade_rt.h C ABI and fail (never skip) when it is absent.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import jaderaytracerendering_amd as J  # noqa: E402
+from jaderaytracerendering_amd import backend as B  # noqa: E402
+
+ORACLE_LIB = os.path.join(ROOT, "oracle", "libjade_oracle.so")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _ensure_built():
+    """CPU-side libraries are cheap to (re)build; the HIP library is built by __graft_entry__.build()."""
+    if not os.path.exists(ORACLE_LIB):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    if not os.path.exists(os.path.join(ROOT, "jaderaytracerendering_amd", "lib", "libjade_host.so")):
+        subprocess.check_call(["make", "-C", ROOT, "host"])
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    _ensure_built()
+    return B.Backend(ORACLE_LIB)
+
+
+@pytest.fixture(scope="session")
+def hip():
+    _ensure_built()
+    be = B.hip()  # raises if libjade_hip.so is missing: no silent fallback
+    assert be.name == "hip-gfx950"
+    assert be.device_count() >= 1, "no HIP device visible"
+    return be
+
+
+_scene_cache = {}
+
+
+def config_scene(name):
+    _ensure_built()
+    if name not in _scene_cache:
+        _scene_cache[name] = J.build_config(name)
+    return _scene_cache[name]
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.sqrt(((a - b) ** 2).sum()) / max(np.sqrt((b ** 2).sum()), 1e-300))
+
+
+COUNTER_KEYS = ("rays_primary", "rays_secondary", "nodes_visited", "tris_tested", "shaded_hits", "samples")
+
+
+def counters(st):
+    return {k: getattr(st, k) for k in COUNTER_KEYS}
