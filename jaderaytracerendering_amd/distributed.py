@@ -55,8 +55,10 @@ def gather_framebuffer(tiles, width, height, dst=0, group=None):
     import torch
     import torch.distributed as dist
 
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
+    if dist.is_available() and dist.is_initialized():
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+    else:
+        world, rank = 1, 0  # single process, single GPU: nothing to exchange
     n_max = max_owned(width, height, world)
     buf = torch.zeros((n_max, TILE, TILE, 3), dtype=tiles.dtype, device=tiles.device)
     buf[: tiles.shape[0]] = tiles
