@@ -71,3 +71,27 @@ COUNTER_KEYS = ("rays_primary", "rays_secondary", "nodes_visited", "tris_tested"
 
 def counters(st):
     return {k: getattr(st, k) for k in COUNTER_KEYS}
+
+
+@pytest.fixture(scope="session")
+def fpm():
+    """ctypes handle on tests/native/fpmath_export.c, built with the mandatory flags."""
+    import ctypes
+    out_dir = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "libfpmath_test.so")
+    src = os.path.join(ROOT, "tests", "native", "fpmath_export.c")
+    hdr = os.path.join(ROOT, "include", "jade_fpmath.h")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", "-fno-fast-math",
+                               "-I", os.path.join(ROOT, "include"), "-o", so, src])
+    lib = ctypes.CDLL(so)
+    lib.t_dot.restype = ctypes.c_float
+    lib.t_mixed.restype = ctypes.c_float
+    lib.t_fmin.restype = ctypes.c_float
+    lib.t_fmax.restype = ctypes.c_float
+    lib.t_fmin.argtypes = lib.t_fmax.argtypes = [ctypes.c_float, ctypes.c_float]
+    lib.t_selftest.argtypes = [ctypes.c_float]
+    lib.t_seed.restype = ctypes.c_uint32
+    lib.t_seed.argtypes = [ctypes.c_uint32] * 3
+    return lib

@@ -1,0 +1,101 @@
+"""The drop-in boundary: both libraries export every symbol include/jade_rt.h declares,
+the ctypes mirrors match the C layout, and the product fails loudly without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import B, J, ROOT, config_scene
+from jaderaytracerendering_amd import _abi
+
+
+def _declared_symbols(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return set(re.findall(r"\b(jadeh?_[a-z0-9_]+)\s*\(", text))
+
+
+def test_python_tables_cover_the_headers():
+    assert _declared_symbols("jade_rt.h") == set(_abi.RT_SYMBOLS)
+    assert _declared_symbols("jade_host_c.h") == set(_abi.HOST_SYMBOLS)
+
+
+@pytest.mark.parametrize("which", ["hip", "oracle"])
+def test_library_loads_and_exports_every_symbol(which):
+    path = B.HIP_LIB if which == "hip" else os.path.join(ROOT, "oracle", "libjade_oracle.so")
+    assert os.path.exists(path), f"{path} not built (run __graft_entry__.build())"
+    lib = ctypes.CDLL(path)
+    for name in _abi.RT_SYMBOLS:
+        assert hasattr(lib, name), f"{path} lacks {name}"
+    _abi.bind(lib, _abi.RT_SYMBOLS)
+    assert lib.jade_abi_version() == _abi.JADE_ABI_VERSION
+    assert lib.jade_backend_name().decode() == ("hip-gfx950" if which == "hip" else "oracle-cpu")
+    assert lib.jade_owned_tile_count(1920, 1080, 0, 8) == 1020
+    assert lib.jade_owned_tile_count(33, 17, 1, 4) == 2 and lib.jade_owned_tile_count(33, 17, 3, 4) == 1  # 3x2 tiles
+    assert lib.jade_owned_tile_count(0, 17, 0, 1) == -1
+
+
+def test_struct_layout_matches_the_c_compiler(fpm):
+    out = (ctypes.c_int * 14)()
+    fpm.t_layout(out)
+    # 112 / 40 / 8: sizeof Triangle_cu / BVHNode_cu / Obj_seg measured in SURVEY.md section 2 row 8
+    assert list(out[:3]) == [112, 40, 8]
+    assert list(out[:6]) == [ctypes.sizeof(t) for t in (_abi.Triangle, _abi.BvhNode, _abi.ObjSeg, _abi.SceneDesc,
+                                                          _abi.RenderParams, _abi.Stats)]
+    # offsets SURVEY.md lists: norm@40 emissive@52 brdf@64 reflex@76 rate@84 albedo@96 index@108
+    assert list(out[6:13]) == [40, 52, 64, 76, 84, 96, 108]
+    assert [getattr(_abi.Triangle, f).offset for f in ("norm", "emissive", "brdf", "reflex_mode", "refract_rate",
+                                                       "refract_albedo", "refract_index")] == list(out[6:13])
+    assert out[13] == _abi.BvhNode.aa.offset == 16
+
+
+def test_product_fails_loudly_without_a_gpu():
+    """No CPU fallback: on a box without a HIP device the product returns an error status."""
+    hip = J.hip()
+    try:
+        n = hip.device_count()
+    except B.JadeError as e:
+        assert e.code == _abi.JADE_ERR_DEVICE
+        n = 0
+    if n > 0:
+        pytest.skip("a GPU is present; the no-device path is not reachable")
+    hs, _ = config_scene("tiny")
+    with pytest.raises(B.JadeError) as ei:
+        hip.scene(hs)
+    assert ei.value.code == _abi.JADE_ERR_DEVICE
+
+
+@pytest.mark.parametrize("which", ["oracle", "hip"])
+def test_scene_validation_errors(which, oracle):
+    """Bad arrays are rejected with a status + message, never a crash (no exit() across the ABI)."""
+    be = oracle if which == "oracle" else J.hip()
+    hs, _ = config_scene("tiny")
+
+    def expect(mutator, codes):
+        bad = J.HostScene({k: v.copy() for k, v in hs.a.items()})
+        mutator(bad)
+        with pytest.raises(B.JadeError) as ei:
+            be.scene(bad)
+        assert ei.value.code in codes and str(ei.value)
+
+    inv = (_abi.JADE_ERR_INVALID, _abi.JADE_ERR_UNSUPPORTED)
+    expect(lambda s: s.a["emit"].__setitem__(0, 10 ** 6), inv)
+    expect(lambda s: s.a["mapping"].__setitem__(0, -5), inv)
+    expect(lambda s: s.a["segs"].__setitem__((0, 1), 10 ** 6), inv)
+    expect(lambda s: s.node_i32().__setitem__((1, 0), 10 ** 6), inv)     # child out of range
+    expect(lambda s: s.node_i32().__setitem__((1, 0), 1), inv)            # cycle: root is its own child
+
+    def deep_chain(s):  # a BVH deeper than the 128-entry traversal stack
+        n = 200
+        nodes = np.zeros((2 * n + 2, 10), np.uint32)
+        ni = nodes.view(np.int32)
+        for i in range(1, n + 1):
+            ni[i, 0] = i + 1 if i < n else n + 1
+            ni[i, 1] = n + 1 + i if i < n else 2 * n + 1
+        for j in list(range(n + 1, 2 * n + 2)):
+            ni[j, 2], ni[j, 3] = 1, 0
+        ni[n, 0], ni[n, 1] = n + 1, 2 * n + 1
+        s.a["nodes"] = nodes
+    expect(deep_chain, (_abi.JADE_ERR_UNSUPPORTED,))

@@ -1,0 +1,146 @@
+"""include/jade_fpmath.h: the arithmetic contract both backends rely on (CPU side)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+
+def _call1(fn, x):
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.empty_like(x)
+    fn(x.ctypes.data_as(ctypes.c_void_p), y.ctypes.data_as(ctypes.c_void_p), len(x))
+    return y
+
+
+def _ulps(got, ref64):
+    ref32 = ref64.astype(np.float32)
+    ulp = np.spacing(np.abs(ref32)).astype(np.float64)
+    return np.abs(got.astype(np.float64) - ref64) / np.maximum(ulp, 1e-300)
+
+
+def test_selftest_detects_contraction(fpm):
+    assert fpm.t_selftest(1.0) == 0
+
+
+def test_wang_hash_known_answers(fpm):
+    """shaders/fshader_render.fsh:82-98, recomputed independently in Python integers."""
+    def wang(s):
+        s = ((s ^ 61) ^ (s >> 16)) & 0xFFFFFFFF
+        s = (s * 9) & 0xFFFFFFFF
+        s = s ^ (s >> 4)
+        s = (s * 0x27d4eb2d) & 0xFFFFFFFF
+        return s ^ (s >> 15)
+    for (x, y, f) in [(0, 0, 0), (3, 5, 0), (1919, 1079, 0), (7, 7, 12)]:
+        seed = ((x * 1973 + y * 9277 + f * 26699) | 1) & 0xFFFFFFFF
+        assert fpm.t_seed(x, y, f) == seed
+        n = 64
+        states = np.zeros(n, np.uint32)
+        u = np.zeros(n, np.float32)
+        fpm.t_rand(ctypes.c_uint32(seed), states.ctypes.data_as(ctypes.c_void_p), u.ctypes.data_as(ctypes.c_void_p), n)
+        s = seed
+        for i in range(n):
+            s = wang(s)
+            assert states[i] == s
+            assert u[i] == np.float32(np.float32(s) * np.float32(2.0 ** -32))
+        assert (u >= 0).all() and (u <= 1).all()
+
+
+def test_sincos_accuracy(fpm):
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.random(200000) * 6.2831852, rng.normal(size=20000) * 50, [0.0, 3.1415926, 6.2831852]]).astype(np.float32)
+    s = np.empty_like(x)
+    c = np.empty_like(x)
+    fpm.t_sincos(x.ctypes.data_as(ctypes.c_void_p), s.ctypes.data_as(ctypes.c_void_p), c.ctypes.data_as(ctypes.c_void_p), len(x))
+    assert np.abs(s - np.sin(x.astype(np.float64))).max() < 2.5e-7
+    assert np.abs(c - np.cos(x.astype(np.float64))).max() < 2.5e-7
+    assert np.abs(s * s + c * c - 1).max() < 5e-7
+
+
+def test_log2_exp2_pow_accuracy(fpm):
+    rng = np.random.default_rng(2)
+    a = np.exp(rng.uniform(-60, 60, 200000)).astype(np.float32)
+    a = a[(a < 0.97) | (a > 1.03)]  # away from log2 ~ 0 where ulps of the result explode
+    assert _ulps(_call1(fpm.t_log2, a), np.log2(a.astype(np.float64))).max() < 2.0
+    y = rng.uniform(-120, 120, 200000).astype(np.float32)
+    assert _ulps(_call1(fpm.t_exp2, y), np.exp2(y.astype(np.float64))).max() < 2.0
+    # gamma curve of the tone mapper: powf(c, 1/2.2), c in [0, 1]
+    c = rng.random(200000).astype(np.float32)
+    g = np.full_like(c, np.float32(1.0 / 2.2))
+    out = np.empty_like(c)
+    fpm.t_pow(c.ctypes.data_as(ctypes.c_void_p), g.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), len(c))
+    ref = np.power(c.astype(np.float64), g.astype(np.float64))
+    assert _ulps(out[c > 1e-30], ref[c > 1e-30]).max() < 6.0
+    # the BSSRDF profile: powf(float(e), -r/d), r/d up to ~20
+    x = (-rng.random(200000) * 20).astype(np.float32)
+    e = np.full_like(x, np.float32(2.71828182846))
+    fpm.t_pow(e.ctypes.data_as(ctypes.c_void_p), x.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), len(x))
+    ref = np.power(e.astype(np.float64), x.astype(np.float64))
+    assert (np.abs(out - ref) / ref).max() < 1e-6
+
+
+def test_pow_special_values(fpm):
+    inf, nan = np.float32(np.inf), np.float32(np.nan)
+    a = np.array([0, 0, -1, inf, inf, 1, 5, nan, 2, 0.5, 2, 0.5], np.float32)
+    b = np.array([0.45, -1, 0.45, 0.45, -1, nan, 0, 1, inf, inf, -inf, -inf], np.float32)
+    out = np.empty_like(a)
+    fpm.t_pow(a.ctypes.data_as(ctypes.c_void_p), b.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), len(a))
+    exp = [0, inf, nan, inf, 0, 1, 1, nan, inf, 0, 0, inf]
+    for g, e in zip(out, exp):
+        assert (np.isnan(g) and np.isnan(e)) or g == e
+    assert _call1(fpm.t_exp2, [-149, -160, 128, 127])[0] == np.float32(2.0 ** -149)
+    sp = _call1(fpm.t_log2, [0.0, -1.0, np.inf, 1.0, 1e-40])
+    assert sp[0] == -np.inf and np.isnan(sp[1]) and sp[2] == np.inf and sp[3] == 0 and abs(sp[4] - np.log2(1e-40)) < 1e-3
+
+
+def test_atan2_asin_accuracy(fpm):
+    rng = np.random.default_rng(3)
+    y = rng.normal(size=200000).astype(np.float32)
+    x = rng.normal(size=200000).astype(np.float32)
+    out = np.empty_like(x)
+    fpm.t_atan2(y.ctypes.data_as(ctypes.c_void_p), x.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), len(x))
+    assert np.abs(out - np.arctan2(y.astype(np.float64), x.astype(np.float64))).max() < 6e-7
+    v = (rng.random(200000) * 2 - 1).astype(np.float32)
+    assert np.abs(_call1(fpm.t_asin, v) - np.arcsin(v.astype(np.float64))).max() < 4e-7
+    assert np.isnan(_call1(fpm.t_asin, [1.5])[0])
+    ax = np.array([0, 0, 1, -1, 0], np.float32)
+    ay = np.array([0, 1, 0, 0, -1], np.float32)
+    fpm.t_atan2(ay.ctypes.data_as(ctypes.c_void_p), ax.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), 5)
+    assert np.allclose(out[:5], [0, np.pi / 2, 0, np.pi, -np.pi / 2], atol=1e-6)
+
+
+def test_floor_and_minmax_nan_rules(fpm):
+    x = np.array([-2.5, -2.0, -0.5, 0.0, 0.5, 2.0, 2.5, 1e9, -1e9, 3e10], np.float32)
+    assert np.array_equal(_call1(fpm.t_floor, x), np.floor(x))
+    nan = float("nan")
+    # CUDA min(float,float)/max(float,float) = fminf/fmaxf: the NaN operand is dropped (PathTrace.cu:767-768)
+    assert fpm.t_fmin(nan, 2.0) == 2.0 and fpm.t_fmin(2.0, nan) == 2.0 and fpm.t_fmax(nan, -1.0) == -1.0
+    assert fpm.t_fmin(1.0, 2.0) == 1.0 and fpm.t_fmax(1.0, 2.0) == 2.0
+
+
+def test_fma_placement_emulated(fpm):
+    """dot contracts exactly as nvcc does: fma(e,f, fma(c,d, a*b)) (PathTrace.cu:257-259)."""
+    rng = np.random.default_rng(4)
+
+    def f32(x):
+        return np.float32(x)
+
+    def fma32(a, b, c):  # exact product in float64 (24x24 bits fit), one rounding of the sum... not exact for all c
+        return f32(np.float64(a) * np.float64(b) + np.float64(c))
+
+    for _ in range(2000):
+        a, b = rng.normal(size=3).astype(np.float32), rng.normal(size=3).astype(np.float32)
+        got = fpm.t_dot(a.ctypes.data_as(ctypes.c_void_p), b.ctypes.data_as(ctypes.c_void_p))
+        want = fma32(a[2], b[2], fma32(a[1], b[1], f32(a[0] * b[0])))
+        # float64 emulation of fma is exact unless the sum needs more than 53 bits: allow 1 ulp
+        assert abs(np.float64(got) - np.float64(want)) <= np.spacing(np.abs(want))
+
+
+def test_double_rounding_is_innocuous_for_division():
+    """The reference writes 1.0/x, x/3.0 and (u-0.5)*2 with double literals; fp64-then-round == fp32."""
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.normal(size=500000), np.exp(rng.uniform(-80, 80, 500000))]).astype(np.float32)
+    x = x[x != 0]
+    assert np.array_equal((1.0 / x.astype(np.float64)).astype(np.float32), np.float32(1.0) / x)
+    assert np.array_equal((x.astype(np.float64) / 3.0).astype(np.float32), x / np.float32(3.0))
+    u = rng.random(500000).astype(np.float32)
+    assert np.array_equal((2.0 * (u.astype(np.float64) - 0.5)).astype(np.float32), np.float32(2.0) * (u - np.float32(0.5)))

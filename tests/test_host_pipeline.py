@@ -1,0 +1,202 @@
+"""Host scene pipeline (the repo's own C++): meshes, normalisation quirk, SAH BVH conventions, IO."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from conftest import B, J, config_scene
+from jaderaytracerendering_amd import host as H
+
+
+def _edges_manifold(idx):
+    e = np.concatenate([idx[:, [0, 1]], idx[:, [1, 2]], idx[:, [2, 0]]])
+    e.sort(axis=1)
+    _, counts = np.unique(e, axis=0, return_counts=True)
+    return (counts == 2).all()
+
+
+def _proc_mesh(kind, param, seed=0, tmp=None):
+    path = os.path.join(tmp, f"{kind}{param}.obj")
+    assert H.host_lib().jadeh_write_proc_obj(kind.encode(), param, seed, path.encode()) == 0
+    v, f = [], []
+    for line in open(path):
+        t = line.split()
+        if t and t[0] == "v":
+            v.append([float(x) for x in t[1:4]])
+        elif t and t[0] == "f":
+            f.append([int(x) - 1 for x in t[1:4]])
+    return np.array(v, np.float32), np.array(f, np.int64), path
+
+
+def test_geodesic_is_closed_and_counts(tmp_path):
+    for f in (1, 3, 8):
+        v, idx, _ = _proc_mesh("geodesic", f, tmp=str(tmp_path))
+        assert len(idx) == 20 * f * f and len(v) == 10 * f * f + 2
+        assert _edges_manifold(idx)
+        assert np.allclose(np.linalg.norm(v, axis=1), 1, atol=1e-6)
+
+
+def test_statue_stand_ins_are_watertight(tmp_path):
+    v, idx, _ = _proc_mesh("statue", 12, 7, str(tmp_path))
+    assert len(idx) == 20 * 144 and _edges_manifold(idx)
+    assert abs(v[:, 2].min()) < 1e-6          # stands on z = 0 (up axis before the reference's Rx(-90))
+    v, idx, _ = _proc_mesh("dragon", 12, 7, str(tmp_path))
+    assert _edges_manifold(idx) and np.ptp(v[:, 0]) > 1.4 * np.ptp(v[:, 1])
+    # the benchmark meshes: ~70k and ~870k triangles (BASELINE.json configs)
+    assert abs(20 * 59 * 59 - 70000) / 70000 < 0.01 and abs(20 * 209 * 209 - 870000) / 870000 < 0.01
+
+
+def test_obj_loader_matches_procedural_path_and_slash_handling(tmp_path):
+    v, idx, path = _proc_mesh("statue", 5, 3, str(tmp_path))
+    mat = H.jade_material()
+    t = H.transform_matrix((-90, 0, 0), (0, -0.52, 0.5), (0.3, 0.3, 0.3))
+    b1, b2 = J.SceneBuilder(), J.SceneBuilder()
+    b1.add_proc("statue", 5, mat, t, True, seed=3)
+    b2.add_obj(path, mat, t, True)
+    s1, s2 = b1.build(), b2.build()
+    # %.9g round-trips float32 exactly, so the two scenes are identical bit for bit
+    assert np.array_equal(s1.a["triangles"], s2.a["triangles"]) and np.array_equal(s1.a["nodes"], s2.a["nodes"])
+    # readObj turns '/' into ' ' and keeps the first three integers (PathTrace.cu:388-406)
+    p = tmp_path / "slash.obj"
+    p.write_text("# c\nv 0 0 0\nv 1 0 0\nv 0 1 0\nv 0 0 1\nf 1// 2// 3//\nf 1 3 4\n")
+    b3 = J.SceneBuilder()
+    b3.add_obj(str(p), mat)
+    s3 = b3.build()
+    assert s3.n_triangles == 2
+    # "f a/b/c" takes a, b, c of the FIRST vertex as the three indices (the reference's mis-parse,
+    # SURVEY.md 9.1); out-of-range indices are an error here instead of undefined behaviour
+    q = tmp_path / "bad.obj"
+    q.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1/9/9 2/9/9 3/9/9\n")
+    with pytest.raises(RuntimeError, match="out of range"):
+        b3.add_obj(str(q), mat)
+    with pytest.raises(RuntimeError, match="open failed"):
+        b3.add_obj(str(tmp_path / "missing.obj"), mat)
+
+
+def test_normalisation_quirk_is_reproduced():
+    """PathTrace.cu:399-400: maxy/maxz/miny/minz come from maxx/minx and the LAST vertex only."""
+    verts = np.array([[0, 0, 0], [4, 0, 0], [0, 10, 0], [1, 1, 1]], np.float32)   # last vertex (1,1,1)
+    idx = np.array([[0, 1, 2], [0, 1, 3]])
+    b = J.SceneBuilder()
+    b.add_mesh(verts, idx, H.material(), None, True)
+    s = b.build()
+    # maxx=4, minx=0; maxy=max(4,1)=4, miny=min(0,1)=0; same for z -> extent 4, centre (2,2,2)
+    want = (verts - 2.0) / 4.0
+    got = np.unique(s.vertices().reshape(-1, 3), axis=0)
+    assert np.allclose(np.unique(want, axis=0), got, atol=1e-7)
+    assert got[:, 1].max() == 2.0   # y = 10 was NOT used for the extent: (10-2)/4
+
+
+@pytest.mark.parametrize("name", ["tiny", "tinyjade", "C1", "C2"])
+def test_bvh_invariants(name):
+    hs, _ = config_scene(name)
+    ni, nf = hs.node_i32(), hs.node_f32()
+    v = hs.vertices()
+    nT = hs.n_triangles
+    assert tuple(ni[0, :3]) == (255, 128, 30)          # the dummy node 0, PathTrace.cu:1557-1563
+    seen = np.zeros(nT, np.int32)
+    stack, depth_max = [(1, 1)], 0
+    while stack:
+        i, d = stack.pop()
+        depth_max = max(depth_max, d)
+        l, r, n, first = ni[i, :4]
+        aa, bb = nf[i, 4:7], nf[i, 7:10]
+        if n > 0:
+            assert 1 <= n <= 8 and l == 0 and r == 0                     # leaves hold <= 8 triangles
+            seen[first:first + n] += 1
+            tv = v[first:first + n].reshape(-1, 3)
+            assert np.array_equal(tv.min(0), aa) and np.array_equal(tv.max(0), bb)   # tight boxes
+        else:
+            assert l > 0 and r > 0                                       # children > 0, 0 = null
+            for c in (l, r):
+                assert (nf[c, 4:7] >= aa).all() and (nf[c, 7:10] <= bb).all()      # child boxes inside parent
+                stack.append((c, d + 1))
+    assert (seen == 1).all()                                             # every triangle in exactly one leaf
+    assert depth_max == hs.bvh_depth < 127
+    # bookkeeping arrays: mapping is a permutation, prefix sums restart per object and are areas
+    assert np.array_equal(np.sort(hs.a["mapping"]), np.arange(nT))
+    tri_obj = hs.tri_i32()[:, 0]
+    for o, (b, e) in enumerate(hs.a["segs"]):
+        sorted_pos = hs.a["mapping"][b:e + 1]
+        assert (tri_obj[sorted_pos] == o).all()
+        p = v[sorted_pos]
+        area = 0.5 * np.linalg.norm(np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0]), axis=1)
+        assert np.allclose(np.cumsum(area.astype(np.float64)), hs.a["prefix"][b:e + 1], rtol=2e-4)
+    em = hs.tri_f32()[:, 13:16]
+    assert np.array_equal(np.flatnonzero((em > 1.5e-4).any(1)), hs.a["emit"])          # PathTrace.cu:1597
+
+
+def test_bvh_equals_brute_force(oracle):
+    """hitBVH over the SAH tree == hitArray over all triangles (one giant leaf) on random rays."""
+    b = J.SceneBuilder()
+    cfg = b.config("tinyjade")
+    tree, flat = b.build(8), b.build(10 ** 9)
+    assert flat.n_nodes == 2 and np.array_equal(np.sort(tree.vertices().reshape(-1, 9), axis=0),
+                                                np.sort(flat.vertices().reshape(-1, 9), axis=0))
+    rng = np.random.default_rng(11)
+    n = 4000
+    o = (rng.random((n, 3)) * 2 - 1).astype(np.float32) * 1.5
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    skip = np.full(n, -1, np.int32)
+    with oracle.scene(tree) as st, oracle.scene(flat) as sf:
+        it, dt, pt, _ = st.trace_rays(o, d, skip)
+        i_f, df, pf, _ = sf.trace_rays(o, d, skip)
+    assert np.array_equal(it >= 0, i_f >= 0) and (it >= 0).sum() > 300
+    h = it >= 0
+    # same triangle (compare by vertices: the two scenes order triangles differently) at the same distance
+    assert np.array_equal(dt[h].view(np.uint32), df[h].view(np.uint32))
+    assert np.array_equal(tree.vertices()[it[h]], flat.vertices()[i_f[h]])
+
+
+def test_camera_and_transform_matrices():
+    eye, cam = H.camera_orbit(4.0, 0.0, 0.0)
+    assert np.allclose(eye, [0, 0, 4], atol=1e-6)
+    m = cam.reshape(4, 4)                      # rows are glm columns: right, up, -forward, eye
+    assert np.allclose(m[:3, :3], np.eye(3), atol=1e-6) and np.allclose(m[3, :3], eye)
+    eye, cam = H.camera_orbit(3.0, 30.0, 45.0, (0.1, 0.2, 0.0))
+    r = cam.reshape(4, 4)[:3, :3]
+    assert np.allclose(r @ r.T, np.eye(3), atol=1e-6) and np.isclose(np.linalg.norm(eye), 3.0, atol=1e-5)
+    fwd = -r[2]
+    want = np.array([0.1, 0.2, 0.0]) - eye
+    assert np.allclose(fwd, want / np.linalg.norm(want), atol=1e-5)
+    t = H.transform_matrix((0, 0, 90), (1, 2, 3), (2, 2, 2)).reshape(4, 4)   # [col][row]
+    p = np.array([1, 0, 0, 1.0]) @ t
+    assert np.allclose(p[:3], [1, 4, 3], atol=1e-5)       # scale 2, Rz(90): x -> y, then translate
+
+
+def test_image_writers(tmp_path):
+    bgr = (np.arange(5 * 3 * 3) % 256).astype(np.uint8).reshape(3, 5, 3)   # 5 wide: rows unpadded, as the reference
+    H.write_bmp(str(tmp_path / "a.bmp"), bgr)
+    raw = (tmp_path / "a.bmp").read_bytes()
+    assert raw[:2] == b"BM" and len(raw) == 54 + 45
+    size, _, _, off = struct.unpack("<IHHI", raw[2:14])
+    hs, w, h, planes, bpp = struct.unpack("<IiiHH", raw[14:30])
+    assert (size, off, hs, w, h, planes, bpp) == (99, 54, 40, 5, 3, 1, 24) and raw[54:] == bgr.tobytes()
+    H.write_ppm(str(tmp_path / "a.ppm"), bgr)
+    ppm = (tmp_path / "a.ppm").read_bytes()
+    assert ppm.startswith(b"P6\n5 3\n255\n") and ppm[-15:] == bgr[0, :, ::-1].tobytes()   # top-down RGB
+    rgb = np.linspace(0, 1, 45, dtype=np.float32).reshape(3, 5, 3)
+    H.write_pfm(str(tmp_path / "a.pfm"), rgb)
+    pfm = (tmp_path / "a.pfm").read_bytes()
+    assert pfm.startswith(b"PF\n5 3\n-1.0\n") and pfm[-180:] == rgb.tobytes()
+
+
+def test_render_args_round_trip(tmp_path):
+    """render_args.txt (PathTrace.cu:1487-1525): objects, materials, camera in; same scene out."""
+    _, _, obj = _proc_mesh("statue", 4, 9, str(tmp_path))
+    eye, cam = H.camera_orbit(4.0, 10.0, 20.0)
+    t = H.transform_matrix((0, 30, 0), (0.5, 0, 0), (2, 2, 2))
+    m = H.jade_material()
+    lines = [" ".join(f"{x:.9g}" for x in eye)]
+    lines += [" ".join(f"{x:.9g}" for x in cam[4 * c:4 * c + 4]) for c in range(4)]
+    lines += ["1", os.path.basename(obj)]
+    lines += [" ".join(f"{x:.9g}" for x in t[4 * c:4 * c + 4]) for c in range(4)]
+    lines += ["0 0 0", "0.02 0.02 0.02", "1", "1", "0.1 0.1 0.1", "0.3 0.3 0.3", "2.66", "1"]
+    (tmp_path / "render_args.txt").write_text("\n".join(lines) + "\n")
+    b = J.SceneBuilder()
+    cfg = b.load_render_args(str(tmp_path / "render_args.txt"))
+    assert np.array_equal(np.array(cfg.eye, np.float32), eye) and np.array_equal(np.array(cfg.camera, np.float32), cam)
+    b2 = J.SceneBuilder()
+    b2.add_obj(obj, m, t, True)
+    assert np.array_equal(b.build().a["triangles"], b2.build().a["triangles"])

@@ -1,0 +1,176 @@
+"""Hand-derived closed-form checks that pin the oracle (the reference ships no tests).
+
+Each expectation is derived from PathTrace.cu's formulas, not from running the oracle."""
+import numpy as np
+import pytest
+
+from conftest import B, J, config_scene, counters
+from jaderaytracerendering_amd import host as H
+
+WHITE = dict(brdf=(0.6, 0.5, 0.4))
+
+
+def _scene(tris, mats, env=(0, 0, 0)):
+    b = J.SceneBuilder()
+    for verts, m in zip(tris, mats):
+        v = np.asarray(verts, np.float32).reshape(-1, 3)
+        b.add_mesh(v, np.arange(len(v)).reshape(-1, 3), m)
+    b.set_env_constant(*env)
+    return b.build()
+
+
+def _cam_down_z(w=16, spp=1, eye=(0, 0, 4)):
+    e, cam = H.camera_orbit(4.0, 0.0, 0.0)
+    p = B.make_params(w, w, spp, eye, cam, threads=2)
+    return p
+
+
+def test_hit_triangle_distances_and_skip(oracle):
+    """hitTriangle (PathTrace.cu:705-754): distance = dot(P - o, dhat), two-sided, source skipped by index."""
+    hs = _scene([[[-1, -1, 0], [1, -1, 0], [0, 1, 0]], [[-1, -1, -2], [1, -1, -2], [0, 1, -2]]],
+                [H.material(**WHITE), H.material(**WHITE)])
+    v = hs.vertices()
+    near = int(np.flatnonzero(v[:, 0, 2] == 0)[0])
+    far = 1 - near
+    o = np.array([[0, 0, 3], [0, 0, 3], [0, 0, -5], [0, 0, 3], [5, 5, 3], [0, 0, 3], [0.25, -0.5, 3]], np.float32)
+    d = np.array([[0, 0, -1], [0, 0, -2], [0, 0, 1], [0, 0, 1], [0, 0, -1], [1, 0, 0], [0, 0, -1]], np.float32)
+    skip = np.array([-1, near, -1, -1, -1, -1, -1], np.int32)
+    with oracle.scene(hs) as sc:
+        idx, dist, pt, st = sc.trace_rays(o, d, skip)
+    assert list(idx) == [near, far, far, -1, -1, -1, near]
+    assert dist[0] == 3.0 and np.array_equal(pt[0], [0, 0, 0])       # exact: all values are small dyadics
+    assert dist[1] == 5.0                                             # unnormalised direction, world-space distance
+    assert dist[2] == 3.0 and dist[6] == 3.0 and np.array_equal(pt[6], [0.25, -0.5, 0])
+    assert st.rays_secondary == 7 and st.tris_tested == 2 * 7 - 1     # one test skipped by index
+
+
+def test_sky_only_and_emitter_seen_directly(oracle):
+    """A miss returns the environment (PathTrace.cu:1443-1445); a primary hit on a light returns
+    2 x emissive: Le plus the loop's own emissive break (PathTrace.cu:917-919, 1451; quirk 7)."""
+    light = H.material(emissive=(3, 2, 1), brdf=(0.3, 0.3, 0.3))
+    hs = _scene([[[-50, -50, 0], [50, -50, 0], [0, 80, 0]]], [light], env=(0.25, 0.5, 0.75))
+    p = _cam_down_z(8, 2)
+    with oracle.scene(hs) as sc:
+        rgb, bgr, st = sc.render(p)
+    assert np.array_equal(rgb, np.broadcast_to(np.float32([6, 4, 2]), rgb.shape))
+    assert st.rays_primary == st.samples == 8 * 8 * 2 and st.rays_secondary == 0 and st.shaded_hits == st.samples
+    # camera turned away: sky only; bilinear blend of a constant map is the constant (to rounding)
+    e, cam = H.camera_orbit(4.0, 0.0, 180.0)
+    q = B.make_params(8, 8, 2, (0, 0, -4), cam)
+    q.eye[:] = [0, 0, 4]
+    cam2 = cam.copy()
+    q.camera[:] = list(cam2)
+    with oracle.scene(hs) as sc:
+        rgb, bgr, st = sc.render(q)
+    assert np.allclose(rgb, [0.25, 0.5, 0.75], rtol=3e-7) and st.rays_secondary == 0 and st.shaded_hits == 0
+    # tone mapping of the sky pixel, PathTrace.cu:680-682, 1461-1473, in float64
+    c = np.array([0.25, 0.5, 0.75])
+    a = (c * (2.51 * c + 0.03)) / (c * (2.43 * c + 0.59) + 0.14)
+    want = np.floor(255 * a ** (1 / 2.2))[::-1]
+    assert np.abs(bgr[0, 0].astype(int) - want).max() <= 1
+
+
+def test_diffuse_plane_under_constant_sky_expectation(oracle):
+    """Diffuse branch with no emitters (PathTrace.cu:1302-1322): uniform-sphere direction flipped to the
+    outgoing side, weight fr*|cos|*2*pi, fr = brdf/pi, E|cos| = 1/2  =>  E[pixel] = brdf * sky.
+    The indirect ray (RR 0.9) leaves the lone plane and ends the path without adding light."""
+    hs = _scene([[[-60, -60, 0], [60, -60, 0], [0, 90, 0]]], [H.material(**WHITE)], env=(2.0, 2.0, 2.0))
+    p = _cam_down_z(32, 64)
+    with oracle.scene(hs) as sc:
+        rgb, _, st = sc.render(p)
+    mean = rgb.reshape(-1, 3).mean(0)
+    PI = 3.1415926
+    want = np.array(WHITE["brdf"]) / PI * 0.5 * 2 * PI * 2.0
+    assert np.allclose(mean, want, rtol=0.01)
+    n = st.samples
+    assert st.shaded_hits == n                                   # one vertex per sample
+    assert abs((st.rays_secondary - n) / n - 0.9) < 0.01         # env ray always, indirect ray w.p. RR_RATE
+
+
+def test_mirror_plane_expectation(oracle):
+    """Mirror branch (PathTrace.cu:1365-1405): with prob 0.9 reflect, miss, L = sky*fr*(k/(0.9/pi)),
+    fr = brdf/pi, k = 1  =>  every surviving sample = sky*brdf/0.9 and E[pixel] = sky*brdf."""
+    m = H.material(brdf=(0.6, 0.5, 0.4), reflex_mode=1)
+    hs = _scene([[[-60, -60, 0], [60, -60, 0], [0, 90, 0]]], [m], env=(2.0, 2.0, 2.0))
+    p = _cam_down_z(32, 64)
+    with oracle.scene(hs) as sc:
+        rgb, _, st = sc.render(p)
+    assert np.allclose(rgb.reshape(-1, 3).mean(0), 2.0 * np.array(m.brdf[:]), rtol=0.01)
+    one = _cam_down_z(32, 1)
+    with oracle.scene(hs) as sc:
+        r1, _, _ = sc.render(one)
+    vals = np.unique(np.round(r1[..., 0] / (2.0 * 0.6 / 0.9), 4))
+    assert set(vals) <= {0.0, 1.0}                                # RR kills or scales by exactly 1/0.9
+
+
+def test_direct_light_estimator_expectation(oracle):
+    """NEE weight (PathTrace.cu:1294-1297): E * fr * |n.l * nl.l| / |l|^4 * area per emitter triangle.
+    Small light far above a diffuse plane: E[direct] ~= E*fr*cos_s*cos_l*A/d^2 (solid-angle form)."""
+    floor = H.material(brdf=(0.5, 0.5, 0.5))
+    light = H.material(emissive=(100, 100, 100), brdf=(0, 0, 0))
+    s = 0.05
+    hs = _scene([[[-60, -60, 0], [60, -60, 0], [0, 90, 0]],
+                 [[-s, -s, 2], [s, -s, 2], [s, s, 2], [-s, -s, 2], [s, s, 2], [-s, s, 2]]],
+                [floor, light], env=(0, 0, 0))
+    assert len(hs.a["emit"]) == 2
+    e, cam = H.camera_orbit(4.0, 0.0, 0.0)
+    p = B.make_params(8, 8, 256, (0.0, 0.0, 1.0), cam, threads=2)   # eye below the light, looking at the floor
+    with oracle.scene(hs) as sc:
+        rgb, _, st = sc.render(p)
+    centre = rgb[3:5, 3:5, 0].mean()
+    PI = 3.1415926
+    want = 100 * (0.5 / PI) * (2 * s) ** 2 / 2.0 ** 2     # cos = 1 straight below, d = 2
+    assert abs(centre - want) / want < 0.05
+    assert st.rays_secondary >= 3 * st.samples            # 2 shadow rays + env ray per diffuse vertex
+
+
+def test_partition_progressive_and_determinism(oracle):
+    hs, cfg = config_scene("tinyjade")
+    p = B.params_from_config(cfg, spp=3)
+    p.width, p.height = 40, 24
+    with oracle.scene(hs) as sc:
+        full, fb, st = sc.render(p)
+        again, _, st2 = sc.render(p)
+        assert np.array_equal(full.view(np.uint32), again.view(np.uint32)) and counters(st) == counters(st2)
+        acc = np.zeros_like(full)
+        tot = {k: 0 for k in counters(st)}
+        for r in range(3):
+            q = B.params_from_config(cfg, spp=3, tile_rank=r, tile_nranks=3)
+            q.width, q.height = 40, 24
+            part, _, s = sc.render(q)
+            acc += part
+            for k, v in counters(s).items():
+                tot[k] += v
+        assert np.array_equal(acc.view(np.uint32), full.view(np.uint32)) and tot == counters(st)
+        sc.begin(p)
+        sc.step(1)
+        sc.step(2)
+        prog, pb = sc.resolve()
+        assert np.array_equal(prog.view(np.uint32), full.view(np.uint32)) and np.array_equal(pb, fb)
+    for threads in (1, 3):   # the thread count must not change anything
+        q = B.params_from_config(cfg, spp=3, threads=threads)
+        q.width, q.height = 40, 24
+        with oracle.scene(hs) as sc:
+            t, _, s = sc.render(q)
+        assert np.array_equal(t.view(np.uint32), full.view(np.uint32)) and counters(s) == counters(st)
+
+
+def test_empty_and_degenerate_inputs(oracle):
+    hs, cfg = config_scene("tiny")
+    with oracle.scene(hs) as sc:
+        idx, dist, pt, st = sc.trace_rays(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), np.zeros(0, np.int32))
+        assert len(idx) == 0 and st.rays_secondary == 0
+        # zero direction: NaNs flow through the slab test (PathTrace.cu:484-494, 764-765) and nothing is hit
+        idx, _, _, _ = sc.trace_rays(np.zeros((1, 3), np.float32), np.zeros((1, 3), np.float32), np.array([-1], np.int32))
+        assert idx[0] == -1
+        p = B.params_from_config(cfg, spp=0)
+        with pytest.raises(B.JadeError):
+            sc.render(p)
+        p = B.params_from_config(cfg, spp=1, tile_rank=2, tile_nranks=2)
+        with pytest.raises(B.JadeError):
+            sc.render(p)
+        # 1x1 image, more ranks than tiles: rank 1 owns nothing and leaves the buffer untouched
+        q = B.params_from_config(cfg, spp=2, tile_rank=1, tile_nranks=2)
+        q.width = q.height = 1
+        rgb, _, st = sc.render(q)
+        assert st.samples == 0 and (rgb == 0).all()
