@@ -173,6 +173,19 @@ static HitResult hit_array(const jade_scene* s, Ray ray, int l, int r, int src_o
   return res;
 }
 
+/* Diagnostics only (not part of jade_rt.h): histogram of node pops + triangle
+ * tests per hitBVH call in log2 buckets, read by tools/ray_histogram.py. */
+static uint64_t g_visit_hist[2][32];
+void jade_oracle_visit_histogram(uint64_t* out, int reset) {
+  memcpy(out, g_visit_hist, sizeof g_visit_hist);
+  if (reset) memset(g_visit_hist, 0, sizeof g_visit_hist);
+}
+static void hist_add(int which, uint64_t v) {
+  int b = 0;
+  while (v > 1 && b < 31) { v >>= 1; ++b; }
+  __sync_fetch_and_add(&g_visit_hist[which][b], 1);
+}
+
 /* PathTrace.cu:795-859 */
 static HitResult hit_bvh(const jade_scene* s, Ray ray, int src_object_idx, counters* c) {
   HitResult res;
@@ -186,8 +199,10 @@ static HitResult hit_bvh(const jade_scene* s, Ray ray, int src_object_idx, count
   stack[sp] = 1;
   sp++;
   c->nodes_visited++; /* the root record */
+  uint64_t pops = 0, t_before = c->tris_tested;
   while (sp > 0) {
     --sp;
+    ++pops;
     int top = stack[sp];
     const jade_bvh_node* node = &s->nodes[top];
 
@@ -226,6 +241,8 @@ static HitResult hit_bvh(const jade_scene* s, Ray ray, int src_object_idx, count
       stack[sp++] = node->right;
     }
   }
+  hist_add(0, pops);
+  hist_add(1, c->tris_tested - t_before + 1);
   return res;
 }
 
