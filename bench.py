@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="C3")
-    ap.add_argument("--spp-per-step", type=int, default=16, help="samples per pixel per step at N = 1")
+    ap.add_argument("--spp-per-step", type=int, default=64, help="samples per pixel per step at N = 1")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -23,7 +23,7 @@
  *     to the bit on CPU and GPU;
  *   - the RNG is the reference's own deterministic generator from its GLSL
  *     integrator (shaders/fshader_render.fsh:82-98): a Wang hash iterated on
- *     a per-pixel 32-bit state.
+ *     a 32-bit state seeded per pixel and per sample.
  *
  * Nothing here is an intersection routine, a traversal or a shading rule:
  * those are restated independently by the oracle and by the HIP kernels.
@@ -133,8 +133,8 @@ JADE_HD jvec3 jade_transform(jvec3 v, float f4, const float* m) {
 
 /* ------------------------------------------------------------------- RNG */
 
-/* shaders/fshader_render.fsh:82-98.  One 32-bit state per pixel; the state
- * survives across all samples of that pixel. */
+/* shaders/fshader_render.fsh:82-98.  One 32-bit state per (pixel, sample): the
+ * frame term advances with the sample index (see JADE_SAMPLE_LANES in jade_rt.h). */
 JADE_HD uint32_t jade_rng_seed(uint32_t px, uint32_t py, uint32_t frame) {
   return (px * 1973u + py * 9277u + frame * 26699u) | 1u;
 }

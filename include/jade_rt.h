@@ -54,6 +54,19 @@ extern "C" {
 #define JADE_BVH_STACK_CAPACITY 128 /* traversal stack entries */
 #define JADE_MAX_FULL_REFLEX_TIME 32
 
+/* Sample scheduling (this ABI's definition; the reference races 31 cuRAND
+ * states and is not reproducible).  Sample s (0-based, counted
+ * across render_step calls) of pixel (x, y) draws from its own Wang-hash
+ * stream seeded (x*1973 + y*9277 + (frame + s)*26699) | 1 — the reference's
+ * GLSL seed (fshader_render.fsh:82-85) with the frame counter advanced per
+ * sample, which is what its progressive preview does (one sample per frame,
+ * fshader_preview.fsh:82-85, 402-403).  Samples are therefore independent work
+ * items.  A pixel's radiance is summed in JADE_SAMPLE_LANES interleaved
+ * partial sums (sample s goes to lane s % JADE_SAMPLE_LANES, in increasing s)
+ * which are added in lane order at resolve time: the result does not depend
+ * on how samples are batched into steps or on the tile partition. */
+#define JADE_SAMPLE_LANES 32
+
 /* == Triangle_cu, PathTrace.cu:327-338 (112 bytes). */
 typedef struct jade_triangle {
   int32_t obj_idx;
@@ -107,7 +120,7 @@ typedef struct jade_scene_desc {
 typedef struct jade_render_params {
   int32_t width, height; /* RENDER_WIDTH / RENDER_HEIGHT, run-time here */
   int32_t spp;           /* samples per pixel rendered by this call */
-  uint32_t frame;        /* RNG frame counter (seed term), normally 0 */
+  uint32_t frame;        /* RNG frame counter of sample 0 (seed term), normally 0 */
   float eye[3];          /* eye_dv */
   float camera[16];      /* camera_transform_dv, [col][row] memory order */
   /* image partition: this call renders the 16x16 tiles whose row-major id
@@ -158,7 +171,7 @@ void jade_scene_destroy(jade_scene* scene);
 int jade_render(jade_scene* scene, const jade_render_params* params, float* out_rgb,
                 uint8_t* out_bgr8, jade_stats* stats);
 
-/* Progressive form: the per-pixel RNG state and radiance sums persist on the
+/* Progressive form: the sample counter and the radiance sums persist on the
  * backend between calls, so N calls of spp samples equal one call of N*spp
  * (the reference's own running-mean preview, fshader_preview.fsh:402-403, is
  * the model).  begin() resets the accumulation; step() adds `spp` samples to

@@ -47,17 +47,21 @@ struct DevScene {
   uint32_t root_ref;
 };
 
-// Per-pixel path state, structure of arrays over the rank's owned pixels
-// (pixel p = owned_tile * 256 + ly * 16 + lx).  `nslots` = n_emit + 2 ray
-// slots per pixel: [0, n_emit) shadow rays, n_emit = environment-visibility
-// ray, n_emit + 1 = indirect ray; single-ray stages use slot 0.
+// Path records, structure of arrays.  Samples are independent work items
+// (jade_rt.h, JADE_SAMPLE_LANES): record r = lane * npx + pixel carries the
+// samples s = lane, lane + 32, lane + 64, ... of owned pixel `pixel`
+// (pixel = owned_tile * 256 + ly * 16 + lx), one after the other, so a rank
+// has npix = npx * JADE_SAMPLE_LANES paths in flight.  `nslots` = n_emit + 2
+// ray slots per record: [0, n_emit) shadow rays, n_emit = environment-
+// visibility ray, n_emit + 1 = indirect ray; single-ray stages use slot 0.
 struct PathState {
-  int32_t npix;
+  int32_t npix;         // number of path records (= npx * JADE_SAMPLE_LANES)
+  int32_t npx;          // owned pixels (tile-padded)
   int32_t nslots;
-  uint32_t* rng;        // Wang-hash state
-  uint32_t* done;       // samples finished
+  uint32_t* rng;        // Wang-hash state of the sample in flight
+  uint32_t* done;       // samples this record has finished
   uint32_t* stage;      // stage | depth << 8 | flags << 16
-  float* sum;           // [3][npix] running radiance sum over samples
+  float* sum;           // [3][npix] this lane's partial radiance sum
   float* thr;           // [3][npix] throughput (product of pushed rates)
   float* acc;           // [3][npix] radiance gathered along the current path
   float* le;            // [3][npix] emission at the primary hit
@@ -97,10 +101,17 @@ struct RenderConst {
   double two_over_w, two_over_h, aspect;
 };
 
+// Work counters are sharded: a block adds into shard blockIdx % JADE_CTR_SHARDS
+// (one 64-B line each) so that a million waves do not serialise on one address
+// (same-address device atomics retire at ~12 ns each, MI355X_MICROARCH.md
+// "fanin"); the host sums the shards after a step.
+#define JADE_CTR_SHARDS 256
 struct DevCounters {
   unsigned long long rays_primary, rays_secondary, nodes_visited, tris_tested, shaded_hits, samples;
-  unsigned long long active_paths;  // pixels still working after the last shade pass
+  unsigned long long pad[2];
 };
+#define JADE_TRACE_CHUNK 512 /* most rays a wave claims per queue atomic */
+#define JADE_REFILL_MIN 16    /* idle lanes in a wave that trigger a refill */
 
 static __device__ __forceinline__ jvec3 ld3(const float* a, int npix, int p) {
   return jv(a[p], a[npix + p], a[2 * npix + p]);

@@ -30,10 +30,10 @@
 // ------------------------------------------------------------------ kernels --
 
 struct QueueCtl {
-  uint32_t count;  // rays emitted by the last shade pass
-  uint32_t next;   // next unclaimed queue entry (trace)
-  uint32_t fp_bad; // jade_fp_selftest result (checked once)
-  uint32_t pad;
+  uint32_t count;   // rays emitted by the last shade pass
+  uint32_t next;    // next unclaimed queue entry (trace)
+  uint32_t active;  // records with rays in flight after the last shade pass
+  uint32_t fp_bad;  // jade_fp_selftest result (checked once)
 };
 
 static __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t* total) {
@@ -60,21 +60,54 @@ __global__ void k_selftest(QueueCtl* q, float one) { q->fp_bad = (uint32_t)jade_
 __global__ void k_init(PathState P, RenderConst R, const int32_t* tile_ids) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P.npix) return;
-  int t = p >> 8, l = p & 255;
+  int pix = p % P.npx;
+  int t = pix >> 8, l = pix & 255;
   int tid = tile_ids[t];
   int x = (tid % R.tiles_x) * JADE_TILE_SIZE + (l & 15);
   int y = (tid / R.tiles_x) * JADE_TILE_SIZE + (l >> 4);
   bool valid = x < R.width && y < R.height;
-  P.rng[p] = jade_rng_seed((uint32_t)x, (uint32_t)y, R.frame);
   P.done[p] = 0;
   P.stage[p] = valid ? ST_IDLE : ST_INVALID;
   st3(P.sum, P.npix, p, jv(0, 0, 0));
 }
 
-__global__ __launch_bounds__(256) void k_shade(DevScene S, PathState P, RenderConst R, const int32_t* tile_ids,
-                                               uint32_t target_spp, uint32_t* queue, QueueCtl* qc, DevCounters* ctr) {
+// Lists every record that has work in this step (samples left to start, or a
+// path suspended by a previous step): the input of the first shade pass.
+__global__ __launch_bounds__(256) void k_arm(PathState P, uint32_t target_spp, uint32_t* active_out, QueueCtl* qc) {
+  __shared__ uint32_t sh_cnt[4], sh_base;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  bool want = false;
+  if (p < P.npix) {
+    const uint32_t word = P.stage[p], st = word & 255u;
+    if (st != ST_INVALID) {
+      const uint32_t lane_m = (uint32_t)p / (uint32_t)P.npx;
+      want = st != ST_IDLE || lane_m + JADE_SAMPLE_LANES * P.done[p] < target_spp;
+    }
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const unsigned long long m = __ballot(want);
+  const uint32_t off = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+  if (lane == 0) sh_cnt[w] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t tot = sh_cnt[0] + sh_cnt[1] + sh_cnt[2] + sh_cnt[3];
+    sh_base = tot ? atomicAdd(&qc->active, tot) : 0u;
+  }
+  __syncthreads();
+  if (want) {
+    uint32_t b = sh_base + off;
+    for (int i = 0; i < w; ++i) b += sh_cnt[i];
+    active_out[b] = (uint32_t)p;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_shade(DevScene S, PathState P, RenderConst R, const int32_t* tile_ids,
+                                               uint32_t target_spp, const uint32_t* active_in, uint32_t n_active,
+                                               uint32_t* active_out, uint32_t* queue, QueueCtl* qc, DevCounters* ctr) {
+  __shared__ uint32_t sh_rays[4], sh_act[4], sh_base[2];
+  const uint32_t t_idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int npix = P.npix;
+  const int p = t_idx < n_active ? (int)active_in[t_idx] : npix;
   ShadeCtx c;
   c.n_emit_rays = 0;
   c.c_primary = c.c_secondary = c.c_shaded = c.c_samples = 0;
@@ -147,12 +180,17 @@ __global__ __launch_bounds__(256) void k_shade(DevScene S, PathState P, RenderCo
         continue;
       }
       if (st == ST_IDLE) {
-        if (done >= target_spp) break;
+        // this record's samples are lane, lane + 32, ...: done of them so far
+        const uint32_t lane_m = (uint32_t)p / (uint32_t)P.npx;
+        const uint32_t sidx = lane_m + JADE_SAMPLE_LANES * done;
+        if (sidx >= target_spp) break;
         // camera ray, PathTrace.cu:1428-1437
-        int t = p >> 8, l = p & 255;
+        int pixi = p - (int)lane_m * P.npx;
+        int t = pixi >> 8, l = pixi & 255;
         int tid = tile_ids[t];
         int x = (tid % R.tiles_x) * JADE_TILE_SIZE + (l & 15);
         int y = (tid / R.tiles_x) * JADE_TILE_SIZE + (l >> 4);
+        c.rng = jade_rng_seed((uint32_t)x, (uint32_t)y, R.frame + sidx);
         float fx = (float)x + jade_rand(&c.rng);
         double lo = -1.0 + R.two_over_w * ((double)fx - 0.5);
         float left_offset = (float)(lo * R.aspect);
@@ -184,33 +222,50 @@ __global__ __launch_bounds__(256) void k_shade(DevScene S, PathState P, RenderCo
     st3(P.out, npix, p, c.out);
   }
 
-  // (c) queue the emitted rays: wave-level exclusive scan, one atomic per wave
-  const int lane = threadIdx.x & 63;
+  // (c) queue the emitted rays and list this record for the next pass: wave
+  // scans, then ONE atomic per block and list (not per wave: see DevCounters)
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   uint32_t total;
-  uint32_t off = wave_excl_scan((uint32_t)c.n_emit_rays, &total);
-  uint32_t base = 0;
-  if (total) {
-    if (lane == 0) base = atomicAdd(&qc->count, total);
-    base = __shfl(base, 0, 64);
-    if (c.n_emit_rays) {
-      const int used = (st == ST_DIFFUSE || st == ST_BSSRDF) ? P.nslots : 1;
-      uint32_t w = base + off;
-      for (int k = 0; k < used; ++k)
-        if (P.hit[(size_t)k * npix + p] == -1) queue[w++] = (uint32_t)k * (uint32_t)npix + (uint32_t)p;
+  const uint32_t off = wave_excl_scan((uint32_t)c.n_emit_rays, &total);
+  const bool live = c.n_emit_rays > 0;
+  const unsigned long long am = __ballot(live);
+  const uint32_t aoff = (uint32_t)__popcll(am & ((1ull << lane) - 1ull));
+  if (lane == 0) {
+    sh_rays[w] = total;
+    sh_act[w] = (uint32_t)__popcll(am);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t tr = sh_rays[0] + sh_rays[1] + sh_rays[2] + sh_rays[3];
+    uint32_t ta = sh_act[0] + sh_act[1] + sh_act[2] + sh_act[3];
+    sh_base[0] = tr ? atomicAdd(&qc->count, tr) : 0u;
+    sh_base[1] = ta ? atomicAdd(&qc->active, ta) : 0u;
+  }
+  __syncthreads();
+  if (live) {
+    uint32_t wq = sh_base[0] + off, wa = sh_base[1] + aoff;
+    for (int i = 0; i < w; ++i) {
+      wq += sh_rays[i];
+      wa += sh_act[i];
     }
+    active_out[wa] = (uint32_t)p;
+    const int used = (st == ST_DIFFUSE || st == ST_BSSRDF) ? P.nslots : 1;
+    for (int k = 0; k < used; ++k)
+      if (P.hit[(size_t)k * npix + p] == -1) queue[wq++] = (uint32_t)k * (uint32_t)npix + (uint32_t)p;
   }
   unsigned long long s0 = wave_sum_u32(c.c_primary), s1 = wave_sum_u32(c.c_secondary), s2 = wave_sum_u32(c.c_shaded),
                      s3 = wave_sum_u32(c.c_samples);
   if (lane == 0) {
-    if (s0) atomicAdd(&ctr->rays_primary, s0);
-    if (s1) atomicAdd(&ctr->rays_secondary, s1);
-    if (s2) atomicAdd(&ctr->shaded_hits, s2);
-    if (s3) atomicAdd(&ctr->samples, s3);
+    DevCounters* cs = ctr + (blockIdx.x % JADE_CTR_SHARDS);
+    if (s0) atomicAdd(&cs->rays_primary, s0);
+    if (s1) atomicAdd(&cs->rays_secondary, s1);
+    if (s2) atomicAdd(&cs->shaded_hits, s2);
+    if (s3) atomicAdd(&cs->samples, s3);
   }
 }
 
 __global__ __launch_bounds__(JADE_TRACE_BLOCK) void k_trace(DevScene S, PathState P, const uint32_t* queue, QueueCtl* qc,
-                                                           uint32_t* spill, DevCounters* ctr) {
+                                                           uint32_t* spill, DevCounters* ctr, uint32_t chunk) {
   __shared__ uint32_t lds_stack[JADE_LDS_STACK * JADE_TRACE_BLOCK];
   const int lane = threadIdx.x & 63;
   const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -223,41 +278,73 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK) void k_trace(DevScene S, PathStat
   const int npix = P.npix;
   const size_t plane = (size_t)P.nslots * npix;
   uint32_t V = 0, T = 0;
+  // wave-local chunk of the queue: [lbase, lend) (wave-uniform)
+  uint32_t lbase = 0, lend = 0;
+  bool queue_empty = false;
+  bool active = false;
+  uint32_t my_k = 0, my_p = 0;
+  RayState r;
   for (;;) {
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&qc->next, 64u);
-    base = __shfl(base, 0, 64);
-    if (base >= n) break;
-    uint32_t i = base + lane;
-    if (i < n) {
-      uint32_t e = queue[i];
-      uint32_t k = e / (uint32_t)npix, p = e - k * (uint32_t)npix;
-      jvec3 o = ld3(P.org, npix, p);
-      const float* db = P.dir + (size_t)k * npix + p;
-      jvec3 d = jv(db[0], db[plane], db[2 * plane]);
-      TraceHit h = trace_ray(S, o, d, P.skip[p], stk, V, T);
-      P.hit[(size_t)k * npix + p] = h.index;
-      float* hb = P.hpt + (size_t)k * npix + p;
-      hb[0] = h.point.x;
-      hb[plane] = h.point.y;
-      hb[2 * plane] = h.point.z;
+    // ---- refill idle lanes once enough of them are idle (or all are)
+    const unsigned long long idle = __ballot(!active);
+    const int n_idle = __popcll(idle);
+    if (n_idle >= JADE_REFILL_MIN && !queue_empty) {
+      if (lbase >= lend) {
+        uint32_t nb = 0;
+        if (lane == 0) nb = atomicAdd(&qc->next, chunk);
+        nb = __shfl(nb, 0, 64);
+        if (nb >= n) {
+          queue_empty = true;
+          lbase = lend = n;
+        } else {
+          lbase = nb;
+          lend = nb + chunk < n ? nb + chunk : n;
+        }
+      }
+      const uint32_t avail = lend - lbase;
+      const uint32_t take = (uint32_t)n_idle < avail ? (uint32_t)n_idle : avail;
+      const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+      if (!active && rank < take) {
+        const uint32_t e = queue[lbase + rank];
+        my_k = e / (uint32_t)npix;
+        my_p = e - my_k * (uint32_t)npix;
+        const jvec3 o = ld3(P.org, npix, my_p);
+        const float* db = P.dir + (size_t)my_k * npix + my_p;
+        const jvec3 d = jv(db[0], db[plane], db[2 * plane]);
+        ray_begin(r, S, o, d, P.skip[my_p], V);
+        active = true;
+      }
+      lbase += take;
+    }
+    if (n_idle == 64 && queue_empty) break;  // nothing in flight, nothing left to claim
+    // ---- one primitive per active lane
+    if (active && !ray_step(r, S, stk, V, T)) {
+      P.hit[(size_t)my_k * npix + my_p] = r.best_index;
+      float* hb = P.hpt + (size_t)my_k * npix + my_p;
+      hb[0] = r.best_point.x;
+      hb[plane] = r.best_point.y;
+      hb[2 * plane] = r.best_point.z;
+      active = false;
     }
   }
   unsigned long long sv = wave_sum_u32(V), stt = wave_sum_u32(T);
   if (lane == 0) {
-    if (sv) atomicAdd(&ctr->nodes_visited, sv);
-    if (stt) atomicAdd(&ctr->tris_tested, stt);
+    DevCounters* cs = ctr + (blockIdx.x % JADE_CTR_SHARDS);
+    if (sv) atomicAdd(&cs->nodes_visited, sv);
+    if (stt) atomicAdd(&cs->tris_tested, stt);
   }
 }
 
 // ACESToneMapping + gamma + BGR pack, PathTrace.cu:680-682, 1457-1473.
 __global__ void k_resolve(PathState P, float inv_spp, float* out_rgb, uint8_t* out_bgr) {
-  int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= P.npix) return;
+  int p = blockIdx.x * blockDim.x + threadIdx.x;  // owned pixel
+  if (p >= P.npx) return;
   bool valid = (P.stage[p] & 255u) != ST_INVALID;
   jvec3 m = jv(0, 0, 0);
   if (valid) {
+    // add the JADE_SAMPLE_LANES partial sums in lane order (jade_rt.h)
     jvec3 s = ld3(P.sum, P.npix, p);
+    for (int l = 1; l < JADE_SAMPLE_LANES; ++l) s = jv_add(s, ld3(P.sum, P.npix, l * P.npx + p));
     m = jv(s.x * inv_spp, s.y * inv_spp, s.z * inv_spp);
   }
   if (out_rgb) {
@@ -325,7 +412,7 @@ struct jade_scene {
   jade_render_params rp{};
   RenderConst rc{};
   PathState ps{};
-  DevBuf b_state, b_tiles, b_queue, b_ctl, b_ctr, b_spill, b_out_rgb, b_out_bgr;
+  DevBuf b_state, b_tiles, b_queue, b_active[2], b_ctl, b_ctr, b_spill, b_out_rgb, b_out_bgr;
   std::vector<int32_t> tile_ids;
   int trace_blocks = 0;
   int64_t spp_done = 0;
@@ -465,7 +552,7 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
   if (e == hipSuccess) e = upload(s->b_segs, d->obj_segs, (size_t)d->n_objects);
   if (e == hipSuccess) e = upload(s->b_env, d->env_rgb, (size_t)3 * d->env_width * d->env_height);
   if (e == hipSuccess) e = s->b_ctl.alloc(sizeof(QueueCtl));
-  if (e == hipSuccess) e = s->b_ctr.alloc(sizeof(DevCounters));
+  if (e == hipSuccess) e = s->b_ctr.alloc(sizeof(DevCounters) * JADE_CTR_SHARDS);
   if (e != hipSuccess) {
     delete s;
     return fail(e == hipErrorOutOfMemory ? JADE_ERR_NOMEM : JADE_ERR_DEVICE, std::string("scene upload: ") + hipGetErrorString(e));
@@ -513,7 +600,8 @@ void jade_scene_destroy(jade_scene* s) {
   delete s;
 }
 
-static int setup_state(jade_scene* s, int npix, int nslots) {
+static int setup_state(jade_scene* s, int npx, int nslots) {
+  const int npix = npx * JADE_SAMPLE_LANES;
   // carve every per-pixel array out of one allocation
   size_t words = 0;
   auto take = [&](size_t n) { size_t o = words; words += (n + 63) & ~(size_t)63; return o; };
@@ -526,6 +614,7 @@ static int setup_state(jade_scene* s, int npix, int nslots) {
   uint32_t* b = s->b_state.as<uint32_t>();
   PathState& P = s->ps;
   P.npix = npix;
+  P.npx = npx;
   P.nslots = nslots;
   P.rng = b + o_rng; P.done = b + o_done; P.stage = b + o_stage;
   P.sum = (float*)(b + o_sum); P.thr = (float*)(b + o_thr); P.acc = (float*)(b + o_acc); P.le = (float*)(b + o_le);
@@ -533,6 +622,8 @@ static int setup_state(jade_scene* s, int npix, int nslots) {
   P.skip = (int32_t*)(b + o_skip); P.aux = (float*)(b + o_aux); P.auxi = (int32_t*)(b + o_auxi);
   P.dir = (float*)(b + o_dir); P.hit = (int32_t*)(b + o_hit); P.hpt = (float*)(b + o_hpt);
   HIP_TRY(s->b_queue.alloc(K * N * 4));
+  HIP_TRY(s->b_active[0].alloc(N * 4));
+  HIP_TRY(s->b_active[1].alloc(N * 4));
   if (!s->b_spill.p)
     HIP_TRY(s->b_spill.alloc((size_t)(JADE_BVH_STACK_CAPACITY - JADE_LDS_STACK) * s->trace_blocks * JADE_TRACE_BLOCK * 4));
   return JADE_OK;
@@ -547,8 +638,10 @@ int jade_render_begin(jade_scene* s, const jade_render_params* rp) {
   s->tile_ids.clear();
   for (int id = rp->tile_rank; id < tx * ty; id += rp->tile_nranks) s->tile_ids.push_back(id);
   const int nslots = s->n_emit + 2;
-  const int64_t npix64 = (int64_t)s->tile_ids.size() * 256;
-  if (npix64 * nslots >= ((int64_t)1 << 32)) return fail(JADE_ERR_UNSUPPORTED, "pixels x (emitters + 2) exceeds 2^32 ray slots");
+  const int64_t npx64 = (int64_t)s->tile_ids.size() * 256;
+  const int64_t npix64 = npx64 * JADE_SAMPLE_LANES;
+  if (npix64 * nslots >= ((int64_t)1 << 32) || npix64 >= ((int64_t)1 << 31))
+    return fail(JADE_ERR_UNSUPPORTED, "pixels x sample lanes x (emitters + 2) exceeds 2^32 ray slots");
   s->have_rp = false;
   s->rp = *rp;
   RenderConst& R = s->rc;
@@ -559,16 +652,38 @@ int jade_render_begin(jade_scene* s, const jade_render_params* rp) {
   R.two_over_h = 2.0 / (double)rp->height;
   R.aspect = (double)rp->width / (double)rp->height;
   s->spp_done = 0;
-  if (npix64 == 0) { s->ps.npix = 0; s->have_rp = true; return JADE_OK; }
-  int rc = setup_state(s, (int)npix64, nslots);
+  if (npix64 == 0) { s->ps.npix = 0; s->ps.npx = 0; s->have_rp = true; return JADE_OK; }
+  int rc = setup_state(s, (int)npx64, nslots);
   if (rc) return rc;
   HIP_TRY(upload(s->b_tiles, s->tile_ids.data(), s->tile_ids.size()));
-  HIP_TRY(hipMemsetAsync(s->b_ctr.p, 0, sizeof(DevCounters), s->stream));
+  HIP_TRY(hipMemsetAsync(s->b_ctr.p, 0, sizeof(DevCounters) * JADE_CTR_SHARDS, s->stream));
   hipLaunchKernelGGL(k_init, dim3((unsigned)((npix64 + 255) / 256)), dim3(256), 0, s->stream, s->ps, s->rc, s->b_tiles.as<int32_t>());
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s->stream));
   s->have_rp = true;
   return JADE_OK;
+}
+
+// Rays claimed per queue atomic: large launches amortise the atomic over up to
+// JADE_TRACE_CHUNK rays, small ones keep 64 so every wave gets work.
+static uint32_t trace_chunk(const jade_scene* s, uint32_t n_rays) {
+  uint64_t waves = (uint64_t)s->trace_blocks * (JADE_TRACE_BLOCK / 64);
+  uint64_t per = n_rays / (waves * 64 * 8);  // aim at >= 8 grabs per wave
+  if (per < 1) per = 1;
+  if (per > JADE_TRACE_CHUNK / 64) per = JADE_TRACE_CHUNK / 64;
+  return (uint32_t)per * 64u;
+}
+
+static hipError_t sum_counters(jade_scene* s, DevCounters* out) {
+  std::vector<DevCounters> sh(JADE_CTR_SHARDS);
+  hipError_t e = hipMemcpy(sh.data(), s->b_ctr.p, sizeof(DevCounters) * JADE_CTR_SHARDS, hipMemcpyDeviceToHost);
+  memset(out, 0, sizeof *out);
+  for (const DevCounters& c : sh) {
+    out->rays_primary += c.rays_primary; out->rays_secondary += c.rays_secondary;
+    out->nodes_visited += c.nodes_visited; out->tris_tested += c.tris_tested;
+    out->shaded_hits += c.shaded_hits; out->samples += c.samples;
+  }
+  return e;
 }
 
 // shade/trace passes until a shade pass emits no ray.  The host reads the
@@ -583,16 +698,25 @@ static int run_passes(jade_scene* s, uint32_t target_spp, double* ms_out, double
   HIP_TRY(hipEventCreate(&ta));
   HIP_TRY(hipEventCreate(&tb));
   HIP_TRY(hipEventRecord(ev0, s->stream));
-  const unsigned shade_blocks = (unsigned)((npix + 255) / 256);
   bool trace_pending = false;
   double trace_ms = 0;
   uint64_t launches = 0;
-  for (;;) {
-    HIP_TRY(hipMemsetAsync(qc, 0, 8, s->stream));  // count, next
-    hipLaunchKernelGGL(k_shade, dim3(shade_blocks), dim3(256), 0, s->stream, s->dev, s->ps, s->rc, s->b_tiles.as<int32_t>(),
-                       target_spp, s->b_queue.as<uint32_t>(), qc, s->b_ctr.as<DevCounters>());
-    uint32_t count = 0;
-    HIP_TRY(hipMemcpyAsync(&count, &qc->count, 4, hipMemcpyDeviceToHost, s->stream));
+  // the records with work in this step
+  uint32_t host_ctl[3] = {0, 0, 0};
+  HIP_TRY(hipMemsetAsync(qc, 0, 12, s->stream));
+  hipLaunchKernelGGL(k_arm, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s->stream, s->ps, target_spp,
+                     s->b_active[0].as<uint32_t>(), qc);
+  HIP_TRY(hipMemcpyAsync(host_ctl, qc, 12, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  uint32_t n_active = host_ctl[2];
+  int cur = 0, pass_no = 0;
+  const bool log_passes = getenv("JADE_LOG_PASSES") != nullptr;
+  while (n_active) {
+    HIP_TRY(hipMemsetAsync(qc, 0, 12, s->stream));  // count, next, active
+    hipLaunchKernelGGL(k_shade, dim3((n_active + 255) / 256), dim3(256), 0, s->stream, s->dev, s->ps, s->rc,
+                       s->b_tiles.as<int32_t>(), target_spp, s->b_active[cur].as<uint32_t>(), n_active,
+                       s->b_active[cur ^ 1].as<uint32_t>(), s->b_queue.as<uint32_t>(), qc, s->b_ctr.as<DevCounters>());
+    HIP_TRY(hipMemcpyAsync(host_ctl, qc, 12, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (trace_pending) {
       float t = 0;
@@ -601,13 +725,24 @@ static int run_passes(jade_scene* s, uint32_t target_spp, double* ms_out, double
       launches += 1;
       trace_pending = false;
     }
-    if (count == 0) break;
+    n_active = host_ctl[2];
+    cur ^= 1;
+    if (host_ctl[0] == 0) break;
     HIP_TRY(hipEventRecord(ta, s->stream));
     hipLaunchKernelGGL(k_trace, dim3((unsigned)s->trace_blocks), dim3(JADE_TRACE_BLOCK), 0, s->stream, s->dev, s->ps,
-                       s->b_queue.as<uint32_t>(), qc, s->b_spill.as<uint32_t>(), s->b_ctr.as<DevCounters>());
+                       s->b_queue.as<uint32_t>(), qc, s->b_spill.as<uint32_t>(), s->b_ctr.as<DevCounters>(),
+                       trace_chunk(s, host_ctl[0]));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(tb, s->stream));
     trace_pending = true;
+    if (log_passes) {
+      HIP_TRY(hipEventSynchronize(tb));
+      float t = 0;
+      HIP_TRY(hipEventElapsedTime(&t, ta, tb));
+      fprintf(stderr, "[jade] pass %4d active %9u rays %9u trace %8.3f ms (%7.1f Mray/s)\n", pass_no, n_active, host_ctl[0], t,
+              host_ctl[0] / (t * 1e3));
+    }
+    ++pass_no;
   }
   HIP_TRY(hipEventRecord(ev1, s->stream));
   HIP_TRY(hipEventSynchronize(ev1));
@@ -629,14 +764,14 @@ int jade_render_step(jade_scene* s, int32_t spp, jade_stats* st) {
   HIP_TRY(hipSetDevice(s->device));
   s->spp_done += spp;
   if (s->ps.npix == 0 || spp == 0) return JADE_OK;
-  HIP_TRY(hipMemsetAsync(s->b_ctr.p, 0, sizeof(DevCounters), s->stream));
+  HIP_TRY(hipMemsetAsync(s->b_ctr.p, 0, sizeof(DevCounters) * JADE_CTR_SHARDS, s->stream));
   double ms = 0, trace_ms = 0;
   uint64_t launches = 0;
   int rc = run_passes(s, (uint32_t)s->spp_done, &ms, &trace_ms, &launches);
   if (rc) return rc;
   if (st) {
     DevCounters c{};
-    HIP_TRY(hipMemcpy(&c, s->b_ctr.p, sizeof c, hipMemcpyDeviceToHost));
+    HIP_TRY(sum_counters(s, &c));
     st->rays_primary += c.rays_primary;
     st->rays_secondary += c.rays_secondary;
     st->nodes_visited += c.nodes_visited;
@@ -651,7 +786,7 @@ int jade_render_step(jade_scene* s, int32_t spp, jade_stats* st) {
 }
 
 static int resolve_to(jade_scene* s, float* dev_rgb, uint8_t* dev_bgr, hipStream_t stream) {
-  const int npix = s->ps.npix;
+  const int npix = s->ps.npx;
   if (npix == 0) return JADE_OK;
   float inv = (float)(1.0 / (double)s->spp_done);  // vec3(1.0 / spp), PathTrace.cu:1457
   hipLaunchKernelGGL(k_resolve, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream, s->ps, inv, dev_rgb, dev_bgr);
@@ -663,7 +798,7 @@ int jade_render_resolve(jade_scene* s, float* out_rgb, uint8_t* out_bgr8) {
   if (!s || !s->have_rp) return fail(JADE_ERR_INVALID, "jade_render_begin not called");
   if (s->spp_done <= 0) return fail(JADE_ERR_INVALID, "no samples rendered yet");
   HIP_TRY(hipSetDevice(s->device));
-  const int npix = s->ps.npix;
+  const int npix = s->ps.npx;
   if (npix == 0) return JADE_OK;
   if (out_rgb) HIP_TRY(s->b_out_rgb.alloc((size_t)npix * 12));
   if (out_bgr8) HIP_TRY(s->b_out_bgr.alloc((size_t)npix * 3));
@@ -740,13 +875,13 @@ int jade_trace_rays(jade_scene* s, int32_t n, const float* origins, const float*
   QueueCtl qc{};
   qc.count = (uint32_t)n;
   HIP_TRY(hipMemcpy(s->b_ctl.p, &qc, 8, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemset(s->b_ctr.p, 0, sizeof(DevCounters)));
+  HIP_TRY(hipMemset(s->b_ctr.p, 0, sizeof(DevCounters) * JADE_CTR_SHARDS));
   hipEvent_t ev0, ev1;
   HIP_TRY(hipEventCreate(&ev0));
   HIP_TRY(hipEventCreate(&ev1));
   HIP_TRY(hipEventRecord(ev0, s->stream));
   hipLaunchKernelGGL(k_trace, dim3((unsigned)s->trace_blocks), dim3(JADE_TRACE_BLOCK), 0, s->stream, s->dev, P, b_q.as<uint32_t>(),
-                     s->b_ctl.as<QueueCtl>(), b_spill.as<uint32_t>(), s->b_ctr.as<DevCounters>());
+                     s->b_ctl.as<QueueCtl>(), b_spill.as<uint32_t>(), s->b_ctr.as<DevCounters>(), trace_chunk(s, (uint32_t)n));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(ev1, s->stream));
   HIP_TRY(hipEventSynchronize(ev1));
@@ -772,7 +907,7 @@ int jade_trace_rays(jade_scene* s, int32_t n, const float* origins, const float*
   }
   if (st) {
     DevCounters c{};
-    HIP_TRY(hipMemcpy(&c, s->b_ctr.p, sizeof c, hipMemcpyDeviceToHost));
+    HIP_TRY(sum_counters(s, &c));
     st->rays_secondary += (uint64_t)n;
     st->nodes_visited += c.nodes_visited;
     st->tris_tested += c.tris_tested;

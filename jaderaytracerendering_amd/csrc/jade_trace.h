@@ -10,7 +10,10 @@
 //
 // What is different is how the work is laid out for a 64-lane wavefront:
 //   - one ray per lane, rays taken from a compacted queue by persistent
-//     workgroups (one atomic per wave per 64 rays);
+//     workgroups: a wave claims a chunk with one atomic and refills its idle
+//     lanes from that chunk, so short rays do not leave lanes idle behind long ones;
+//   - the unit of work per loop iteration is one primitive (a node visit or
+//     one triangle test), not a whole 8-triangle leaf;
 //   - the near child is followed directly and only the far child is pushed,
 //     which visits nodes in exactly the reference's order with half the stack
 //     traffic;
@@ -95,68 +98,111 @@ static __device__ __forceinline__ bool tri_test(jvec3 p1, jvec3 p2, jvec3 p3, jv
 
 static __device__ __forceinline__ bool finite_f(float x) { return (jade_f2u(x) & 0x7f800000u) != 0x7f800000u; }
 
-// hitBVH, PathTrace.cu:795-859.  V / T are the exact work counters
-// (node records needed, triangles tested).
-static __device__ __forceinline__ TraceHit trace_ray(const DevScene& S, jvec3 o, jvec3 d, int32_t skip,
-                                                     const LdsStack& stk, uint32_t& V, uint32_t& T) {
-  TraceHit best;
-  best.index = -1;
-  best.dist = JADE_INF_F;
-  best.point = jv(0, 0, 0);
-  const jvec3 inv = jv(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-  const jvec3 dn = jv_normalize(d);
-  const bool exact = !(finite_f(inv.x) && finite_f(inv.y) && finite_f(inv.z)) || !finite_f(o.x) || !finite_f(o.y) ||
-                     !finite_f(o.z);
-  int sp = 0;
-  uint32_t cur = S.root_ref;
+// One lane's traversal state for hitBVH (PathTrace.cu:795-859), advanced ONE
+// primitive per call: either one internal-node visit (both children's slab
+// tests, near-first descent, far child pushed) or one triangle test of the
+// current leaf.  Keeping the unit of work small is what lets a 64-lane wave
+// mix lanes that are deep in a leaf with lanes that are still descending
+// without one serialising the other, and lets finished lanes be refilled.
+struct RayState {
+  jvec3 o, inv, dn;
+  int32_t skip;
+  bool exact;
+  uint32_t cur;          // current ref (internal node or leaf)
+  uint32_t tri_i, tri_n; // leaf cursor: next triangle, end (tri_i < tri_n while inside a leaf)
+  int sp;
+  int32_t best_index;
+  float best_dist;
+  jvec3 best_point;
+};
+
+static __device__ __forceinline__ void ray_begin(RayState& r, const DevScene& S, jvec3 o, jvec3 d, int32_t skip, uint32_t& V) {
+  r.o = o;
+  r.inv = jv(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  r.dn = jv_normalize(d);
+  r.skip = skip;
+  r.exact = !(finite_f(r.inv.x) && finite_f(r.inv.y) && finite_f(r.inv.z)) || !finite_f(o.x) || !finite_f(o.y) || !finite_f(o.z);
+  r.sp = 0;
+  r.best_index = -1;
+  r.best_dist = JADE_INF_F;
+  r.best_point = jv(0, 0, 0);
+  r.cur = S.root_ref;
+  r.tri_i = r.tri_n = 0;
+  if (r.cur & JADE_REF_LEAF) {
+    r.tri_i = (r.cur & 0x7fffffffu) >> 4;
+    r.tri_n = r.tri_i + (r.cur & 15u);
+  }
   V += 1;  // the root record
-  for (;;) {
-    if (cur & JADE_REF_LEAF) {
-      const uint32_t first = (cur & 0x7fffffffu) >> 4, n = cur & 15u;
-      for (uint32_t i = first; i < first + n; ++i) {
-        if ((int32_t)i == skip) continue;
-        const float4 a = S.tverts[3 * (size_t)i], b = S.tverts[3 * (size_t)i + 1], c = S.tverts[3 * (size_t)i + 2];
-        float dist;
-        jvec3 P;
-        T += 1;
-        if (tri_test(jv(a.x, a.y, a.z), jv(b.x, b.y, b.z), jv(c.x, c.y, c.z), o, dn, &dist, &P) && dist < best.dist) {
-          best.index = (int32_t)i;
-          best.dist = dist;
-          best.point = P;
-        }
-      }
-      if (sp == 0) break;
-      cur = stack_pop(stk, --sp);
-    } else {
-      const float4* nd = S.nodes + 4 * (size_t)cur;
-      const float4 a = nd[0], b = nd[1], c = nd[2];
-      const uint4 r = *reinterpret_cast<const uint4*>(nd + 3);
-      float d1 = -1.0f, d2 = -1.0f;
-      if (r.x != JADE_REF_NONE) {
-        V += 1;
-        d1 = slab(o, inv, a.x, a.y, a.z, a.w, b.x, b.y, exact);
-      }
-      if (r.y != JADE_REF_NONE) {
-        V += 1;
-        d2 = slab(o, inv, b.z, b.w, c.x, c.y, c.z, c.w, exact);
-      }
-      if (d1 > 0 && d2 > 0) {
-        if (d1 < d2) {
-          stack_push(stk, sp++, r.y);
-          cur = r.x;
-        } else {
-          stack_push(stk, sp++, r.x);
-          cur = r.y;
-        }
-      } else if (d1 > 0) {
-        cur = r.x;
-      } else if (d2 > 0) {
-        cur = r.y;
-      } else {
-        if (sp == 0) break;
-        cur = stack_pop(stk, --sp);
+}
+
+// Make `ref` current; returns false when the stack is empty (ray finished).
+static __device__ __forceinline__ bool ray_pop(RayState& r, const LdsStack& stk) {
+  if (r.sp == 0) return false;
+  r.cur = stack_pop(stk, --r.sp);
+  if (r.cur & JADE_REF_LEAF) {
+    r.tri_i = (r.cur & 0x7fffffffu) >> 4;
+    r.tri_n = r.tri_i + (r.cur & 15u);
+  }
+  return true;
+}
+static __device__ __forceinline__ void ray_goto(RayState& r, uint32_t ref) {
+  r.cur = ref;
+  if (ref & JADE_REF_LEAF) {
+    r.tri_i = (ref & 0x7fffffffu) >> 4;
+    r.tri_n = r.tri_i + (ref & 15u);
+  }
+}
+
+// Returns false when the ray has finished.
+static __device__ __forceinline__ bool ray_step(RayState& r, const DevScene& S, const LdsStack& stk, uint32_t& V, uint32_t& T) {
+  if (r.tri_i < r.tri_n) {
+    // ---- one triangle of the current leaf (hitArray, PathTrace.cu:776-792)
+    const uint32_t i = r.tri_i++;
+    if ((int32_t)i != r.skip) {
+      const float4 a = S.tverts[3 * (size_t)i], b = S.tverts[3 * (size_t)i + 1], c = S.tverts[3 * (size_t)i + 2];
+      float dist;
+      jvec3 P;
+      T += 1;
+      if (tri_test(jv(a.x, a.y, a.z), jv(b.x, b.y, b.z), jv(c.x, c.y, c.z), r.o, r.dn, &dist, &P) && dist < r.best_dist) {
+        r.best_index = (int32_t)i;
+        r.best_dist = dist;
+        r.best_point = P;
       }
     }
+    if (r.tri_i < r.tri_n) return true;
+    return ray_pop(r, stk);
   }
-  return best;
+  if (r.cur & JADE_REF_LEAF) return ray_pop(r, stk);  // empty leaf (cannot happen for a valid BVH)
+  // ---- one internal node
+  const float4* nd = S.nodes + 4 * (size_t)r.cur;
+  const float4 a = nd[0], b = nd[1], c = nd[2];
+  const uint4 rf = *reinterpret_cast<const uint4*>(nd + 3);
+  float d1 = -1.0f, d2 = -1.0f;
+  if (rf.x != JADE_REF_NONE) {
+    V += 1;
+    d1 = slab(r.o, r.inv, a.x, a.y, a.z, a.w, b.x, b.y, r.exact);
+  }
+  if (rf.y != JADE_REF_NONE) {
+    V += 1;
+    d2 = slab(r.o, r.inv, b.z, b.w, c.x, c.y, c.z, c.w, r.exact);
+  }
+  if (d1 > 0 && d2 > 0) {
+    if (d1 < d2) {
+      stack_push(stk, r.sp++, rf.y);
+      ray_goto(r, rf.x);
+    } else {
+      stack_push(stk, r.sp++, rf.x);
+      ray_goto(r, rf.y);
+    }
+    return true;
+  }
+  if (d1 > 0) {
+    ray_goto(r, rf.x);
+    return true;
+  }
+  if (d2 > 0) {
+    ray_goto(r, rf.y);
+    return true;
+  }
+  return ray_pop(r, stk);
 }

@@ -23,8 +23,11 @@
  *
  * Deliberate, documented departures:
  *   - RNG: the racy cuRAND XORWOW is replaced by the reference's own
- *     deterministic per-pixel Wang hash (shaders/fshader_render.fsh:82-98),
- *     drawn in the textual order of the curand_uniform calls;
+ *     deterministic Wang hash (shaders/fshader_render.fsh:82-98), seeded per
+ *     pixel and per sample (frame term = frame + sample index, as the
+ *     reference's one-sample-per-frame preview does) and drawn in the textual
+ *     order of the curand_uniform calls; a pixel's samples are summed in
+ *     JADE_SAMPLE_LANES interleaved partial sums (see jade_rt.h);
  *   - libm / FMA contraction / texture filtering come from include/jade_fpmath.h
  *     and the bilinear fetch below (CUDA's 8-bit-weight tex2D is unreproducible);
  *   - width/height are run-time; for width != height the NDC x is scaled by
@@ -65,8 +68,7 @@ struct jade_scene {
   /* progressive render state */
   jade_render_params rp;
   int have_rp;
-  uint32_t* rng;    /* per pixel */
-  float* sum;       /* per pixel RGB running sum */
+  float* sum;       /* [pixel][JADE_SAMPLE_LANES][3] partial radiance sums */
   int64_t spp_done;
 };
 
@@ -895,7 +897,7 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
 void jade_scene_destroy(jade_scene* s) {
   if (!s) return;
   free(s->tris); free(s->nodes); free(s->emit); free(s->mapping);
-  free(s->prefix); free(s->segs); free(s->env); free(s->rng); free(s->sum);
+  free(s->prefix); free(s->segs); free(s->env); free(s->sum);
   free(s);
 }
 
@@ -917,12 +919,9 @@ int jade_render_begin(jade_scene* s, const jade_render_params* rp) {
   if (rp->width <= 0 || rp->height <= 0 || rp->tile_nranks <= 0 || rp->tile_rank < 0 || rp->tile_rank >= rp->tile_nranks)
     return fail(JADE_ERR_INVALID, "bad image size or tile partition");
   size_t np = (size_t)rp->width * rp->height;
-  free(s->rng); free(s->sum);
-  s->rng = (uint32_t*)malloc(sizeof(uint32_t) * np);
-  s->sum = (float*)calloc(np * 3, sizeof(float));
-  if (!s->rng || !s->sum) return fail(JADE_ERR_NOMEM, "out of memory");
-  for (int y = 0; y < rp->height; ++y)
-    for (int x = 0; x < rp->width; ++x) s->rng[(size_t)y * rp->width + x] = jade_rng_seed((uint32_t)x, (uint32_t)y, rp->frame);
+  free(s->sum);
+  s->sum = (float*)calloc(np * 3 * JADE_SAMPLE_LANES, sizeof(float));
+  if (!s->sum) return fail(JADE_ERR_NOMEM, "out of memory");
   s->rp = *rp;
   s->have_rp = 1;
   s->spp_done = 0;
@@ -932,6 +931,7 @@ int jade_render_begin(jade_scene* s, const jade_render_params* rp) {
 typedef struct {
   jade_scene* s;
   int spp;
+  int64_t first_sample;
   volatile int* next_row;
   counters c;
 } worker_arg;
@@ -946,11 +946,15 @@ static void* worker(void* p) {
     for (int x = 0; x < rp->width; ++x) {
       if (!owns_pixel(rp, x, y)) continue;
       size_t pi = (size_t)y * rp->width + x;
-      uint32_t rng = s->rng[pi];
-      jvec3 acc = jv(s->sum[3 * pi], s->sum[3 * pi + 1], s->sum[3 * pi + 2]);
-      for (int i = 0; i < a->spp; ++i) acc = jv_add(acc, render_sample(s, rp, x, y, &rng, &a->c));
-      s->rng[pi] = rng;
-      s->sum[3 * pi] = acc.x; s->sum[3 * pi + 1] = acc.y; s->sum[3 * pi + 2] = acc.z;
+      float* part = s->sum + pi * 3 * JADE_SAMPLE_LANES;
+      for (int i = 0; i < a->spp; ++i) {
+        int64_t sidx = a->first_sample + i;
+        uint32_t rng = jade_rng_seed((uint32_t)x, (uint32_t)y, rp->frame + (uint32_t)sidx);
+        jvec3 color = render_sample(s, rp, x, y, &rng, &a->c);
+        float* acc = part + 3 * (sidx % JADE_SAMPLE_LANES);
+        /* final_result = final_result + color (PathTrace.cu:1454), per lane */
+        acc[0] = acc[0] + color.x; acc[1] = acc[1] + color.y; acc[2] = acc[2] + color.z;
+      }
     }
   }
   return NULL;
@@ -984,7 +988,7 @@ int jade_render_step(jade_scene* s, int32_t spp, jade_stats* st) {
   volatile int next_row = 0;
   double t0 = now_ms();
   for (int i = 0; i < nt; ++i) {
-    args[i].s = s; args[i].spp = spp; args[i].next_row = &next_row;
+    args[i].s = s; args[i].spp = spp; args[i].first_sample = s->spp_done; args[i].next_row = &next_row;
     if (nt == 1) worker(&args[i]);
     else pthread_create(&th[i], NULL, worker, &args[i]);
   }
@@ -1008,7 +1012,10 @@ int jade_render_resolve(jade_scene* s, float* out_rgb, uint8_t* out_bgr8) {
     for (int x = 0; x < rp->width; ++x) {
       if (!owns_pixel(rp, x, y)) continue;
       size_t pi = (size_t)y * rp->width + x;
-      jvec3 m = jv(s->sum[3 * pi] * inv, s->sum[3 * pi + 1] * inv, s->sum[3 * pi + 2] * inv);
+      const float* part = s->sum + pi * 3 * JADE_SAMPLE_LANES;
+      jvec3 tot = jv(part[0], part[1], part[2]);
+      for (int l = 1; l < JADE_SAMPLE_LANES; ++l) tot = jv_add(tot, jv(part[3 * l], part[3 * l + 1], part[3 * l + 2]));
+      jvec3 m = jv(tot.x * inv, tot.y * inv, tot.z * inv);
       if (out_rgb) { out_rgb[3 * pi] = m.x; out_rgb[3 * pi + 1] = m.y; out_rgb[3 * pi + 2] = m.z; }
       if (out_bgr8) tonemap_pack(m, out_bgr8 + 3 * pi);
     }
