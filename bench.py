@@ -39,10 +39,12 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="C3")
-    ap.add_argument("--spp-per-step", type=int, default=64, help="samples per pixel per step at N = 1")
+    ap.add_argument("--spp-per-step", type=int, default=256, help="samples per pixel per step at N = 1")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--virtual-ranks", type=int, default=0,
+                    help="development: render rank 0's share of a V-GPU run on this one GPU (partition and spp as at N=V)")
     ap.add_argument("--cpu-spp", type=int, default=8, help="oracle sample: spp over the full frame")
     args = ap.parse_args()
 
@@ -74,9 +76,12 @@ def main():
     build_s = time.time() - t0
     width = args.width or cfg.width
     height = args.height or cfg.height
-    spp_step = args.spp_per_step * world  # weak scaling: fixed work per GPU per step
-    params = B.make_params(width, height, spp_step, list(cfg.eye), list(cfg.camera), tile_rank=rank, tile_nranks=world,
-                           device_id=local_rank)
+    part_world, part_rank = world, rank
+    if args.virtual_ranks > 1 and world == 1:
+        part_world, part_rank = args.virtual_ranks, 0
+    spp_step = args.spp_per_step * part_world  # weak scaling: fixed work per GPU per step
+    params = B.make_params(width, height, spp_step, list(cfg.eye), list(cfg.camera), tile_rank=part_rank,
+                           tile_nranks=part_world, device_id=local_rank)
     scene = hip.scene(hs, device_id=local_rank)
 
     def barrier():
@@ -97,7 +102,7 @@ def main():
     dt = time.perf_counter() - t0
 
     # the single exchange step: gather the framebuffer on rank 0
-    n_owned = hip.owned_tile_count(width, height, rank, world)
+    n_owned = hip.owned_tile_count(width, height, part_rank, part_world)
     tiles = torch.empty((n_owned, D.TILE, D.TILE, 3), dtype=torch.float32, device=dev)
     barrier()
     g0 = time.perf_counter()
@@ -105,10 +110,10 @@ def main():
     frame = D.gather_framebuffer(tiles, width, height) if world > 1 else None
     barrier()
     gather_ms = (time.perf_counter() - g0) * 1e3
-    if world == 1:
+    if world == 1 and part_world == 1:
         frame = D.gather_framebuffer(tiles, width, height)
     frame_ok = True
-    if rank == 0:
+    if rank == 0 and frame is not None:
         frame_ok = bool(torch.isfinite(frame).all().item()) and tuple(frame.shape) == (height, width, 3)
 
     vals = torch.tensor([float(st.rays_primary + st.rays_secondary), float(st.nodes_visited), float(st.tris_tested),
@@ -152,6 +157,7 @@ def main():
                 "spp_per_step": spp_step, "width": width, "height": height, "triangles": hs.n_triangles,
                 "bvh_nodes": hs.n_nodes, "bvh_depth": hs.bvh_depth, "parallelism": f"tiles{world}",
             },
+            "virtual_ranks": part_world if part_world != world else None,
             "rays": rays_all,
             "samples": float(vals[5].item()),
             "gather_ms": gather_ms,
@@ -172,17 +178,37 @@ def main():
         dist.destroy_process_group()
 
 
+def usable_cores():
+    """Cores this process may really use: affinity mask, capped by the cgroup CPU quota."""
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    cores = min(cores, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    cores = min(cores, max(1, q // per))
+            break
+        except Exception:
+            continue
+    return cores
+
+
 def cpu_baseline(hs, cfg, width, height, spp):
     """The oracle (a port: the reference has no CPU integrator) on all host cores."""
     from jaderaytracerendering_amd import backend as B
     lib = os.path.join(ROOT, "oracle", "libjade_oracle.so")
     if not os.path.exists(lib):
         return None
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = usable_cores()
     oracle = B.Backend(lib)
     p = B.make_params(width, height, spp, list(cfg.eye), list(cfg.camera), threads=cores)
     with oracle.scene(hs) as so:

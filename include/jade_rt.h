@@ -64,8 +64,9 @@ extern "C" {
  * items.  A pixel's radiance is summed in JADE_SAMPLE_LANES interleaved
  * partial sums (sample s goes to lane s % JADE_SAMPLE_LANES, in increasing s)
  * which are added in lane order at resolve time: the result does not depend
- * on how samples are batched into steps or on the tile partition. */
-#define JADE_SAMPLE_LANES 32
+ * on how samples are batched into steps, on the tile partition, or on how
+ * many of a pixel's samples a backend keeps in flight at once. */
+#define JADE_SAMPLE_LANES 256
 
 /* == Triangle_cu, PathTrace.cu:327-338 (112 bytes). */
 typedef struct jade_triangle {
@@ -123,8 +124,9 @@ typedef struct jade_render_params {
   uint32_t frame;        /* RNG frame counter of sample 0 (seed term), normally 0 */
   float eye[3];          /* eye_dv */
   float camera[16];      /* camera_transform_dv, [col][row] memory order */
-  /* image partition: this call renders the 16x16 tiles whose row-major id
-   * satisfies id % tile_nranks == tile_rank (single GPU: 0 of 1) */
+  /* image partition: this call renders the 16x16 tiles (tx, ty) with
+   * (tx + ty) % tile_nranks == tile_rank — diagonal interleave, so that an
+   * object's pixels spread over all ranks (single GPU: 0 of 1) */
   int32_t tile_rank, tile_nranks;
   int32_t device_id;     /* HIP device ordinal (ignored by the oracle) */
   int32_t threads;       /* oracle: worker threads (0 = all cores); HIP: ignored */
@@ -183,7 +185,7 @@ int jade_render_resolve(jade_scene* scene, float* out_rgb, uint8_t* out_bgr8);
 
 /* Device-resident resolve for multi-GPU gathers (HIP backend only; the oracle
  * returns JADE_ERR_UNSUPPORTED).  Writes this rank's tiles compactly into
- * device memory: tile t (t-th owned tile in increasing id order) occupies
+ * device memory: tile t (t-th owned tile in increasing row-major id) occupies
  * floats [t*768, (t+1)*768) as 16x16 RGB rows.  `dev_tiles` must hold
  * jade_owned_tile_count()*768 floats.  `stream` is a hipStream_t (0 = null
  * stream).  Out-of-image pixels of edge tiles are written as 0. */

@@ -154,7 +154,8 @@ def assemble_tiles(tiles, width, height, rank, nranks, out=None):
     ty = (height + ts - 1) // ts
     if out is None:
         out = np.zeros((height, width, 3), tiles.dtype)
-    ids = np.arange(rank, tx * ty, nranks)
+    from .distributed import owned_tile_ids
+    ids = owned_tile_ids(width, height, rank, nranks)
     for k, tid in enumerate(ids):
         y0, x0 = (tid // tx) * ts, (tid % tx) * ts
         hh, ww = min(ts, height - y0), min(ts, width - x0)

@@ -32,6 +32,7 @@
 
 #define JADE_LDS_STACK 32 /* traversal stack entries kept in LDS per lane */
 #define JADE_TRACE_BLOCK 256
+#define JADE_RECORD_BUDGET (72ll << 20) /* path records kept in flight per GPU (~250 B each) */
 
 struct DevScene {
   const float4* nodes;        // 4 x float4 per internal node
@@ -48,20 +49,27 @@ struct DevScene {
 };
 
 // Path records, structure of arrays.  Samples are independent work items
-// (jade_rt.h, JADE_SAMPLE_LANES): record r = lane * npx + pixel carries the
-// samples s = lane, lane + 32, lane + 64, ... of owned pixel `pixel`
+// (jade_rt.h, JADE_SAMPLE_LANES): record r = m * npx + pixel (m < rpp) carries
+// the samples s = m, m + rpp, m + 2 rpp, ... of owned pixel `pixel`
 // (pixel = owned_tile * 256 + ly * 16 + lx), one after the other, so a rank
-// has npix = npx * JADE_SAMPLE_LANES paths in flight.  `nslots` = n_emit + 2
-// ray slots per record: [0, n_emit) shadow rays, n_emit = environment-
-// visibility ray, n_emit + 1 = indirect ray; single-ray stages use slot 0.
+// has npix = npx * rpp paths in flight.  rpp (records per pixel, a power of two
+// <= JADE_SAMPLE_LANES) is chosen per render so that npix stays about constant:
+// 32 for a full 1080p frame on one GPU, 256 for an eighth of it - the same
+// number of paths in flight per GPU whatever the tile partition.  Sample s adds
+// into partial sum s % JADE_SAMPLE_LANES of its pixel, which only record
+// s % rpp ever touches, in increasing s: no atomics, and a result that does
+// not depend on rpp.  `nslots` = n_emit + 2 ray slots per record: [0, n_emit)
+// shadow rays, n_emit = environment-visibility ray, n_emit + 1 = indirect
+// ray; single-ray stages use slot 0.
 struct PathState {
-  int32_t npix;         // number of path records (= npx * JADE_SAMPLE_LANES)
+  int32_t npix;         // number of path records (= npx * rpp)
   int32_t npx;          // owned pixels (tile-padded)
+  int32_t rpp;          // records per pixel
   int32_t nslots;
   uint32_t* rng;        // Wang-hash state of the sample in flight
   uint32_t* done;       // samples this record has finished
   uint32_t* stage;      // stage | depth << 8 | flags << 16
-  float* sum;           // [3][npix] this lane's partial radiance sum
+  float* sum;           // [3][JADE_SAMPLE_LANES * npx] partial radiance sums per (lane, pixel)
   float* thr;           // [3][npix] throughput (product of pushed rates)
   float* acc;           // [3][npix] radiance gathered along the current path
   float* le;            // [3][npix] emission at the primary hit
@@ -112,6 +120,7 @@ struct DevCounters {
 };
 #define JADE_TRACE_CHUNK 512 /* most rays a wave claims per queue atomic */
 #define JADE_REFILL_MIN 16    /* idle lanes in a wave that trigger a refill */
+#define JADE_STEPS_PER_CHECK 3 /* traversal units between two refill checks */
 
 static __device__ __forceinline__ jvec3 ld3(const float* a, int npix, int p) {
   return jv(a[p], a[npix + p], a[2 * npix + p]);

@@ -68,7 +68,6 @@ __global__ void k_init(PathState P, RenderConst R, const int32_t* tile_ids) {
   bool valid = x < R.width && y < R.height;
   P.done[p] = 0;
   P.stage[p] = valid ? ST_IDLE : ST_INVALID;
-  st3(P.sum, P.npix, p, jv(0, 0, 0));
 }
 
 // Lists every record that has work in this step (samples left to start, or a
@@ -81,7 +80,7 @@ __global__ __launch_bounds__(256) void k_arm(PathState P, uint32_t target_spp, u
     const uint32_t word = P.stage[p], st = word & 255u;
     if (st != ST_INVALID) {
       const uint32_t lane_m = (uint32_t)p / (uint32_t)P.npx;
-      want = st != ST_IDLE || lane_m + JADE_SAMPLE_LANES * P.done[p] < target_spp;
+      want = st != ST_IDLE || lane_m + (uint32_t)P.rpp * P.done[p] < target_spp;
     }
   }
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -116,17 +115,28 @@ __global__ __launch_bounds__(256) void k_shade(DevScene S, PathState P, RenderCo
   if (st != ST_INVALID) {
     const uint32_t word = P.stage[p];
     const Px px(P, p);
+    // State is loaded and stored by need: a background record (camera ray ->
+    // sky, or -> mirror floor -> sky) touches ~90 B per pass, not the whole
+    // ~230-B record; only records on a multi-bounce path carry thr/acc/le/....
+    const bool on_path = st >= ST_DIFFUSE && st <= ST_REFRACT_EXIT;
     c.rng = P.rng[p];
     c.depth = (word >> 8) & 255u;
     c.flags = word >> 16;
     c.stage = st;
-    c.thr = ld3(P.thr, npix, p);
-    c.acc = ld3(P.acc, npix, p);
-    c.le = ld3(P.le, npix, p);
-    c.obj = P.obj[p];
-    c.src = ld3(P.src, npix, p);
-    c.out = ld3(P.out, npix, p);
-    jvec3 sum = ld3(P.sum, npix, p);
+    c.thr = jv(1, 1, 1);
+    c.acc = jv(0, 0, 0);
+    c.le = jv(0, 0, 0);
+    c.obj = 0;
+    c.src = jv(0, 0, 0);
+    c.out = jv(0, 0, 0);
+    if (on_path) {
+      c.thr = ld3(P.thr, npix, p);
+      c.acc = ld3(P.acc, npix, p);
+      c.le = ld3(P.le, npix, p);
+      c.obj = P.obj[p];
+      c.src = ld3(P.src, npix, p);
+      c.out = ld3(P.out, npix, p);
+    }
     uint32_t done = P.done[p];
     jvec3 l_final;
     bool finished = false;  // a sample ended: colour in `color`
@@ -149,7 +159,7 @@ __global__ __launch_bounds__(256) void k_shade(DevScene S, PathState P, RenderCo
         c.out = jv_neg(d);
         st = ST_VERTEX;
       }
-    } else if (st >= ST_DIFFUSE && st <= ST_REFRACT_EXIT) {
+    } else if (on_path) {
       int r = consume(S, px, c, &l_final);
       if (r == CONSUME_VERTEX) {
         st = ST_VERTEX;
@@ -161,10 +171,18 @@ __global__ __launch_bounds__(256) void k_shade(DevScene S, PathState P, RenderCo
         finished = true;
       }
     }
-    // (b) advance until this pixel has rays in flight or no samples left
+    // (b) advance until this record has rays in flight or no samples left
     for (;;) {
       if (finished) {
-        sum = jv_add(sum, color);  // final_result = final_result + color, :1454
+        // final_result = final_result + color (PathTrace.cu:1454), into the partial sum of
+        // this sample's lane: only this record ever touches it
+        {
+          const uint32_t m = (uint32_t)p / (uint32_t)P.npx;
+          const uint32_t vl = (m + (uint32_t)P.rpp * done) % JADE_SAMPLE_LANES;
+          const int si = (int)(vl * (uint32_t)P.npx) + (p - (int)m * P.npx);
+          const int sn = JADE_SAMPLE_LANES * P.npx;
+          st3(P.sum, sn, si, jv_add(ld3(P.sum, sn, si), color));
+        }
         done += 1;
         c.c_samples += 1;
         finished = false;
@@ -180,9 +198,9 @@ __global__ __launch_bounds__(256) void k_shade(DevScene S, PathState P, RenderCo
         continue;
       }
       if (st == ST_IDLE) {
-        // this record's samples are lane, lane + 32, ...: done of them so far
+        // this record's samples are m, m + rpp, ...: `done` of them so far
         const uint32_t lane_m = (uint32_t)p / (uint32_t)P.npx;
-        const uint32_t sidx = lane_m + JADE_SAMPLE_LANES * done;
+        const uint32_t sidx = lane_m + (uint32_t)P.rpp * done;
         if (sidx >= target_spp) break;
         // camera ray, PathTrace.cu:1428-1437
         int pixi = p - (int)lane_m * P.npx;
@@ -213,13 +231,14 @@ __global__ __launch_bounds__(256) void k_shade(DevScene S, PathState P, RenderCo
     P.rng[p] = c.rng;
     P.done[p] = done;
     P.stage[p] = st | (c.depth << 8) | (c.flags << 16);
-    st3(P.sum, npix, p, sum);
-    st3(P.thr, npix, p, c.thr);
-    st3(P.acc, npix, p, c.acc);
-    st3(P.le, npix, p, c.le);
-    P.obj[p] = c.obj;
-    st3(P.src, npix, p, c.src);
-    st3(P.out, npix, p, c.out);
+    if (st >= ST_DIFFUSE && st <= ST_REFRACT_EXIT) {
+      st3(P.thr, npix, p, c.thr);
+      st3(P.acc, npix, p, c.acc);
+      st3(P.le, npix, p, c.le);
+      P.obj[p] = c.obj;
+      st3(P.src, npix, p, c.src);
+      st3(P.out, npix, p, c.out);
+    }
   }
 
   // (c) queue the emitted rays and list this record for the next pass: wave
@@ -317,14 +336,17 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK) void k_trace(DevScene S, PathStat
       lbase += take;
     }
     if (n_idle == 64 && queue_empty) break;  // nothing in flight, nothing left to claim
-    // ---- one primitive per active lane
-    if (active && !ray_step(r, S, stk, V, T)) {
-      P.hit[(size_t)my_k * npix + my_p] = r.best_index;
-      float* hb = P.hpt + (size_t)my_k * npix + my_p;
-      hb[0] = r.best_point.x;
-      hb[plane] = r.best_point.y;
-      hb[2 * plane] = r.best_point.z;
-      active = false;
+    // ---- a few traversal units per active lane between refill checks
+#pragma unroll 1
+    for (int it = 0; it < JADE_STEPS_PER_CHECK; ++it) {
+      if (active && !ray_step(r, S, stk, V, T)) {
+        P.hit[(size_t)my_k * npix + my_p] = r.best_index;
+        float* hb = P.hpt + (size_t)my_k * npix + my_p;
+        hb[0] = r.best_point.x;
+        hb[plane] = r.best_point.y;
+        hb[2 * plane] = r.best_point.z;
+        active = false;
+      }
     }
   }
   unsigned long long sv = wave_sum_u32(V), stt = wave_sum_u32(T);
@@ -343,8 +365,9 @@ __global__ void k_resolve(PathState P, float inv_spp, float* out_rgb, uint8_t* o
   jvec3 m = jv(0, 0, 0);
   if (valid) {
     // add the JADE_SAMPLE_LANES partial sums in lane order (jade_rt.h)
-    jvec3 s = ld3(P.sum, P.npix, p);
-    for (int l = 1; l < JADE_SAMPLE_LANES; ++l) s = jv_add(s, ld3(P.sum, P.npix, l * P.npx + p));
+    const int sn = JADE_SAMPLE_LANES * P.npx;
+    jvec3 s = ld3(P.sum, sn, p);
+    for (int l = 1; l < JADE_SAMPLE_LANES; ++l) s = jv_add(s, ld3(P.sum, sn, l * P.npx + p));
     m = jv(s.x * inv_spp, s.y * inv_spp, s.z * inv_spp);
   }
   if (out_rgb) {
@@ -445,8 +468,10 @@ int jade_device_count(int* n) {
 int jade_owned_tile_count(int32_t width, int32_t height, int32_t rank, int32_t nranks) {
   if (width <= 0 || height <= 0 || nranks <= 0 || rank < 0 || rank >= nranks) return -1;
   int tx = (width + JADE_TILE_SIZE - 1) / JADE_TILE_SIZE, ty = (height + JADE_TILE_SIZE - 1) / JADE_TILE_SIZE;
-  int total = tx * ty;
-  return (total - rank + nranks - 1) / nranks;
+  int count = 0;
+  for (int y = 0; y < ty; ++y)
+    for (int x = 0; x < tx; ++x) count += (x + y) % nranks == rank;
+  return count;
 }
 
 static int validate_desc(const jade_scene_desc* d, int* depth_out) {
@@ -600,13 +625,13 @@ void jade_scene_destroy(jade_scene* s) {
   delete s;
 }
 
-static int setup_state(jade_scene* s, int npx, int nslots) {
-  const int npix = npx * JADE_SAMPLE_LANES;
+static int setup_state(jade_scene* s, int npx, int rpp, int nslots) {
+  const int npix = npx * rpp;
   // carve every per-pixel array out of one allocation
   size_t words = 0;
   auto take = [&](size_t n) { size_t o = words; words += (n + 63) & ~(size_t)63; return o; };
   const size_t N = (size_t)npix, K = (size_t)nslots;
-  size_t o_rng = take(N), o_done = take(N), o_stage = take(N), o_sum = take(3 * N), o_thr = take(3 * N), o_acc = take(3 * N),
+  size_t o_rng = take(N), o_done = take(N), o_stage = take(N), o_sum = take(3 * (size_t)JADE_SAMPLE_LANES * npx), o_thr = take(3 * N), o_acc = take(3 * N),
          o_le = take(3 * N), o_obj = take(N), o_src = take(3 * N), o_out = take(3 * N), o_org = take(3 * N), o_skip = take(N),
          o_aux = take(3 * N), o_auxi = take(N), o_dir = take(3 * K * N), o_hit = take(K * N), o_hpt = take(3 * K * N);
   HIP_TRY(s->b_state.alloc(words * 4));
@@ -615,6 +640,7 @@ static int setup_state(jade_scene* s, int npx, int nslots) {
   PathState& P = s->ps;
   P.npix = npix;
   P.npx = npx;
+  P.rpp = rpp;
   P.nslots = nslots;
   P.rng = b + o_rng; P.done = b + o_done; P.stage = b + o_stage;
   P.sum = (float*)(b + o_sum); P.thr = (float*)(b + o_thr); P.acc = (float*)(b + o_acc); P.le = (float*)(b + o_le);
@@ -636,12 +662,21 @@ int jade_render_begin(jade_scene* s, const jade_render_params* rp) {
   HIP_TRY(hipSetDevice(s->device));
   const int tx = (rp->width + JADE_TILE_SIZE - 1) / JADE_TILE_SIZE, ty = (rp->height + JADE_TILE_SIZE - 1) / JADE_TILE_SIZE;
   s->tile_ids.clear();
-  for (int id = rp->tile_rank; id < tx * ty; id += rp->tile_nranks) s->tile_ids.push_back(id);
+  for (int y = 0; y < ty; ++y)
+    for (int x = 0; x < tx; ++x)
+      if ((x + y) % rp->tile_nranks == rp->tile_rank) s->tile_ids.push_back(y * tx + x);
   const int nslots = s->n_emit + 2;
   const int64_t npx64 = (int64_t)s->tile_ids.size() * 256;
-  const int64_t npix64 = npx64 * JADE_SAMPLE_LANES;
-  if (npix64 * nslots >= ((int64_t)1 << 32) || npix64 >= ((int64_t)1 << 31))
-    return fail(JADE_ERR_UNSUPPORTED, "pixels x sample lanes x (emitters + 2) exceeds 2^32 ray slots");
+  // records per pixel: keep about JADE_RECORD_BUDGET paths in flight whatever the image share
+  int rpp = JADE_SAMPLE_LANES;
+  while (rpp > 1 && npx64 * rpp > JADE_RECORD_BUDGET) rpp >>= 1;
+  if (const char* e = getenv("JADE_RECORDS_PER_PIXEL")) {  // test hook: results must not depend on it
+    int v = atoi(e);
+    if (v >= 1 && v <= JADE_SAMPLE_LANES && (v & (v - 1)) == 0) rpp = v;
+  }
+  const int64_t npix64 = npx64 * rpp;
+  if (npix64 * nslots >= ((int64_t)1 << 32) || npix64 >= ((int64_t)1 << 31) || npx64 * JADE_SAMPLE_LANES >= ((int64_t)1 << 31))
+    return fail(JADE_ERR_UNSUPPORTED, "pixels x records x (emitters + 2) exceeds the 32-bit ray-slot index");
   s->have_rp = false;
   s->rp = *rp;
   RenderConst& R = s->rc;
@@ -653,7 +688,7 @@ int jade_render_begin(jade_scene* s, const jade_render_params* rp) {
   R.aspect = (double)rp->width / (double)rp->height;
   s->spp_done = 0;
   if (npix64 == 0) { s->ps.npix = 0; s->ps.npx = 0; s->have_rp = true; return JADE_OK; }
-  int rc = setup_state(s, (int)npx64, nslots);
+  int rc = setup_state(s, (int)npx64, rpp, nslots);
   if (rc) return rc;
   HIP_TRY(upload(s->b_tiles, s->tile_ids.data(), s->tile_ids.size()));
   HIP_TRY(hipMemsetAsync(s->b_ctr.p, 0, sizeof(DevCounters) * JADE_CTR_SHARDS, s->stream));
@@ -711,13 +746,20 @@ static int run_passes(jade_scene* s, uint32_t target_spp, double* ms_out, double
   uint32_t n_active = host_ctl[2];
   int cur = 0, pass_no = 0;
   const bool log_passes = getenv("JADE_LOG_PASSES") != nullptr;
+  hipEvent_t sa, sb;
+  float shade_ms = 0;
+  HIP_TRY(hipEventCreate(&sa));
+  HIP_TRY(hipEventCreate(&sb));
   while (n_active) {
     HIP_TRY(hipMemsetAsync(qc, 0, 12, s->stream));  // count, next, active
+    if (log_passes) HIP_TRY(hipEventRecord(sa, s->stream));
     hipLaunchKernelGGL(k_shade, dim3((n_active + 255) / 256), dim3(256), 0, s->stream, s->dev, s->ps, s->rc,
                        s->b_tiles.as<int32_t>(), target_spp, s->b_active[cur].as<uint32_t>(), n_active,
                        s->b_active[cur ^ 1].as<uint32_t>(), s->b_queue.as<uint32_t>(), qc, s->b_ctr.as<DevCounters>());
+    if (log_passes) HIP_TRY(hipEventRecord(sb, s->stream));
     HIP_TRY(hipMemcpyAsync(host_ctl, qc, 12, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
+    if (log_passes) HIP_TRY(hipEventElapsedTime(&shade_ms, sa, sb));
     if (trace_pending) {
       float t = 0;
       HIP_TRY(hipEventElapsedTime(&t, ta, tb));
@@ -739,8 +781,8 @@ static int run_passes(jade_scene* s, uint32_t target_spp, double* ms_out, double
       HIP_TRY(hipEventSynchronize(tb));
       float t = 0;
       HIP_TRY(hipEventElapsedTime(&t, ta, tb));
-      fprintf(stderr, "[jade] pass %4d active %9u rays %9u trace %8.3f ms (%7.1f Mray/s)\n", pass_no, n_active, host_ctl[0], t,
-              host_ctl[0] / (t * 1e3));
+      fprintf(stderr, "[jade] pass %4d active %9u rays %9u shade %7.3f ms trace %8.3f ms (%7.1f Mray/s)\n", pass_no, n_active,
+              host_ctl[0], shade_ms, t, host_ctl[0] / (t * 1e3));
     }
     ++pass_no;
   }

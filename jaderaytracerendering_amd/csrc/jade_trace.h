@@ -98,10 +98,10 @@ static __device__ __forceinline__ bool tri_test(jvec3 p1, jvec3 p2, jvec3 p3, jv
 
 static __device__ __forceinline__ bool finite_f(float x) { return (jade_f2u(x) & 0x7f800000u) != 0x7f800000u; }
 
-// One lane's traversal state for hitBVH (PathTrace.cu:795-859), advanced ONE
-// primitive per call: either one internal-node visit (both children's slab
-// tests, near-first descent, far child pushed) or one triangle test of the
-// current leaf.  Keeping the unit of work small is what lets a 64-lane wave
+// One lane's traversal state for hitBVH (PathTrace.cu:795-859), advanced one
+// small unit per call: either one internal-node visit (both children's slab
+// tests, near-first descent, far child pushed) or up to two triangle tests of
+// the current leaf.  Keeping the unit of work small is what lets a 64-lane wave
 // mix lanes that are deep in a leaf with lanes that are still descending
 // without one serialising the other, and lets finished lanes be refilled.
 struct RayState {
@@ -156,15 +156,28 @@ static __device__ __forceinline__ void ray_goto(RayState& r, uint32_t ref) {
 // Returns false when the ray has finished.
 static __device__ __forceinline__ bool ray_step(RayState& r, const DevScene& S, const LdsStack& stk, uint32_t& V, uint32_t& T) {
   if (r.tri_i < r.tri_n) {
-    // ---- one triangle of the current leaf (hitArray, PathTrace.cu:776-792)
-    const uint32_t i = r.tri_i++;
+    // ---- up to two triangles of the current leaf (hitArray, PathTrace.cu:776-792),
+    // tested in index order; both vertex records are requested before either is used
+    const uint32_t i = r.tri_i;
+    const bool two = i + 1 < r.tri_n;
+    const uint32_t j = two ? i + 1 : i;
+    const float4 a0 = S.tverts[3 * (size_t)i], b0 = S.tverts[3 * (size_t)i + 1], c0 = S.tverts[3 * (size_t)i + 2];
+    const float4 a1 = S.tverts[3 * (size_t)j], b1 = S.tverts[3 * (size_t)j + 1], c1 = S.tverts[3 * (size_t)j + 2];
+    r.tri_i = j + 1;
+    float dist;
+    jvec3 P;
     if ((int32_t)i != r.skip) {
-      const float4 a = S.tverts[3 * (size_t)i], b = S.tverts[3 * (size_t)i + 1], c = S.tverts[3 * (size_t)i + 2];
-      float dist;
-      jvec3 P;
       T += 1;
-      if (tri_test(jv(a.x, a.y, a.z), jv(b.x, b.y, b.z), jv(c.x, c.y, c.z), r.o, r.dn, &dist, &P) && dist < r.best_dist) {
+      if (tri_test(jv(a0.x, a0.y, a0.z), jv(b0.x, b0.y, b0.z), jv(c0.x, c0.y, c0.z), r.o, r.dn, &dist, &P) && dist < r.best_dist) {
         r.best_index = (int32_t)i;
+        r.best_dist = dist;
+        r.best_point = P;
+      }
+    }
+    if (two && (int32_t)j != r.skip) {
+      T += 1;
+      if (tri_test(jv(a1.x, a1.y, a1.z), jv(b1.x, b1.y, b1.z), jv(c1.x, c1.y, c1.z), r.o, r.dn, &dist, &P) && dist < r.best_dist) {
+        r.best_index = (int32_t)j;
         r.best_dist = dist;
         r.best_point = P;
       }

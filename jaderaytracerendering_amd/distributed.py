@@ -3,9 +3,9 @@
 The reference is single-GPU (one `render_pixel` launch, PathTrace.cu:1731).
 Pixels share nothing but the read-only scene and every pixel owns its RNG
 stream, so the image splits into the reference's 16x16 tiles
-(TILE_SIZE, PathTrace.cu:32): rank r renders the tiles whose row-major id is
-congruent to r modulo the world size (interleaved, because cost concentrates
-on the statue).  There is no data-path collective while rendering; the only
+(TILE_SIZE, PathTrace.cu:32): rank r renders the tiles (tx, ty) with
+(tx + ty) % world == r (diagonal interleave, because cost concentrates on the
+statue and a row-major deal degenerates into vertical stripes).  There is no data-path collective while rendering; the only
 exchange is ONE gather of each rank's compact tile buffer to rank 0
 (`torch.distributed.gather`: RCCL over xGMI with backend "nccl", gloo on CPU).
 """
@@ -22,13 +22,14 @@ def tile_grid(width, height):
 
 
 def owned_tile_ids(width, height, rank, nranks):
+    """Row-major ids of the tiles (tx, ty) with (tx + ty) % nranks == rank, increasing (jade_rt.h)."""
     tx, ty = tile_grid(width, height)
-    return np.arange(rank, tx * ty, nranks, dtype=np.int64)
+    ids = np.arange(tx * ty, dtype=np.int64)
+    return ids[(ids % tx + ids // tx) % nranks == rank]
 
 
 def max_owned(width, height, nranks):
-    tx, ty = tile_grid(width, height)
-    return (tx * ty + nranks - 1) // nranks
+    return max(len(owned_tile_ids(width, height, r, nranks)) for r in range(nranks))
 
 
 def pack_tiles(image, rank, nranks):
@@ -70,7 +71,12 @@ def gather_framebuffer(tiles, width, height, dst=0, group=None):
     if rank != dst:
         return None
     tx, ty = tile_grid(width, height)
-    # tile id t lives at parts[t % world][t // world]; lay tiles out in id order, then un-tile
-    stacked = torch.stack(parts, dim=1).reshape(n_max * world, TILE, TILE, 3)[: tx * ty]
+    # put every rank's k-th tile at its row-major id, then un-tile
+    allt = torch.stack(parts, dim=0).reshape(world * n_max, TILE, TILE, 3)
+    src = np.zeros(tx * ty, np.int64)
+    for r in range(world):
+        ids = owned_tile_ids(width, height, r, world)
+        src[ids] = r * n_max + np.arange(len(ids))
+    stacked = allt[torch.from_numpy(src).to(allt.device)]
     frame = stacked.reshape(ty, tx, TILE, TILE, 3).permute(0, 2, 1, 3, 4).reshape(ty * TILE, tx * TILE, 3)
     return frame[:height, :width].contiguous()

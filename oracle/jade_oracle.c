@@ -68,7 +68,7 @@ struct jade_scene {
   /* progressive render state */
   jade_render_params rp;
   int have_rp;
-  float* sum;       /* [pixel][JADE_SAMPLE_LANES][3] partial radiance sums */
+  float* sum;       /* [JADE_SAMPLE_LANES][pixel][3] partial radiance sums (untouched lanes stay unmapped) */
   int64_t spp_done;
 };
 
@@ -902,16 +902,16 @@ void jade_scene_destroy(jade_scene* s) {
 }
 
 static int owns_pixel(const jade_render_params* rp, int x, int y) {
-  int tiles_x = (rp->width + JADE_TILE_SIZE - 1) / JADE_TILE_SIZE;
-  int id = (y / JADE_TILE_SIZE) * tiles_x + x / JADE_TILE_SIZE;
-  return id % rp->tile_nranks == rp->tile_rank;
+  return (x / JADE_TILE_SIZE + y / JADE_TILE_SIZE) % rp->tile_nranks == rp->tile_rank;
 }
 
 int jade_owned_tile_count(int32_t width, int32_t height, int32_t rank, int32_t nranks) {
   if (width <= 0 || height <= 0 || nranks <= 0 || rank < 0 || rank >= nranks) return -1;
   int tx = (width + JADE_TILE_SIZE - 1) / JADE_TILE_SIZE, ty = (height + JADE_TILE_SIZE - 1) / JADE_TILE_SIZE;
-  int total = tx * ty;
-  return (total - rank + nranks - 1) / nranks;
+  int count = 0;
+  for (int y = 0; y < ty; ++y)
+    for (int x = 0; x < tx; ++x) count += (x + y) % nranks == rank;
+  return count;
 }
 
 int jade_render_begin(jade_scene* s, const jade_render_params* rp) {
@@ -937,7 +937,9 @@ typedef struct {
 } worker_arg;
 
 static void* worker(void* p) {
-  worker_arg* a = (worker_arg*)p;
+  worker_arg* shared = (worker_arg*)p;
+  worker_arg local = *shared; /* counters on this thread's stack: no false sharing between workers */
+  worker_arg* a = &local;
   jade_scene* s = a->s;
   const jade_render_params* rp = &s->rp;
   for (;;) {
@@ -946,17 +948,18 @@ static void* worker(void* p) {
     for (int x = 0; x < rp->width; ++x) {
       if (!owns_pixel(rp, x, y)) continue;
       size_t pi = (size_t)y * rp->width + x;
-      float* part = s->sum + pi * 3 * JADE_SAMPLE_LANES;
+      const size_t np = (size_t)rp->width * rp->height;
       for (int i = 0; i < a->spp; ++i) {
         int64_t sidx = a->first_sample + i;
         uint32_t rng = jade_rng_seed((uint32_t)x, (uint32_t)y, rp->frame + (uint32_t)sidx);
         jvec3 color = render_sample(s, rp, x, y, &rng, &a->c);
-        float* acc = part + 3 * (sidx % JADE_SAMPLE_LANES);
+        float* acc = s->sum + 3 * ((size_t)(sidx % JADE_SAMPLE_LANES) * np + pi);
         /* final_result = final_result + color (PathTrace.cu:1454), per lane */
         acc[0] = acc[0] + color.x; acc[1] = acc[1] + color.y; acc[2] = acc[2] + color.z;
       }
     }
   }
+  shared->c = local.c;
   return NULL;
 }
 
@@ -1012,9 +1015,12 @@ int jade_render_resolve(jade_scene* s, float* out_rgb, uint8_t* out_bgr8) {
     for (int x = 0; x < rp->width; ++x) {
       if (!owns_pixel(rp, x, y)) continue;
       size_t pi = (size_t)y * rp->width + x;
-      const float* part = s->sum + pi * 3 * JADE_SAMPLE_LANES;
-      jvec3 tot = jv(part[0], part[1], part[2]);
-      for (int l = 1; l < JADE_SAMPLE_LANES; ++l) tot = jv_add(tot, jv(part[3 * l], part[3 * l + 1], part[3 * l + 2]));
+      const size_t np = (size_t)rp->width * rp->height;
+      jvec3 tot = jv(s->sum[3 * pi], s->sum[3 * pi + 1], s->sum[3 * pi + 2]);
+      for (size_t l = 1; l < JADE_SAMPLE_LANES; ++l) {
+        const float* q = s->sum + 3 * (l * np + pi);
+        tot = jv_add(tot, jv(q[0], q[1], q[2]));
+      }
       jvec3 m = jv(tot.x * inv, tot.y * inv, tot.z * inv);
       if (out_rgb) { out_rgb[3 * pi] = m.x; out_rgb[3 * pi + 1] = m.y; out_rgb[3 * pi + 2] = m.z; }
       if (out_bgr8) tonemap_pack(m, out_bgr8 + 3 * pi);

@@ -32,8 +32,8 @@ def test_library_loads_and_exports_every_symbol(which):
     _abi.bind(lib, _abi.RT_SYMBOLS)
     assert lib.jade_abi_version() == _abi.JADE_ABI_VERSION
     assert lib.jade_backend_name().decode() == ("hip-gfx950" if which == "hip" else "oracle-cpu")
-    assert lib.jade_owned_tile_count(1920, 1080, 0, 8) == 1020
-    assert lib.jade_owned_tile_count(33, 17, 1, 4) == 2 and lib.jade_owned_tile_count(33, 17, 3, 4) == 1  # 3x2 tiles
+    assert lib.jade_owned_tile_count(1920, 1080, 0, 8) == 1020  # 120 x 68 tiles, diagonal deal
+    assert [lib.jade_owned_tile_count(33, 17, r, 4) for r in range(4)] == [1, 2, 2, 1]  # 3x2 tiles, (tx+ty) % 4
     assert lib.jade_owned_tile_count(0, 17, 0, 1) == -1
 
 
