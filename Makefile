@@ -8,7 +8,7 @@ CXX      ?= g++
 # -ffp-contract=off everywhere: include/jade_fpmath.h pins the evaluation order.
 FPFLAGS  := -ffp-contract=off -fno-fast-math
 CXXFLAGS := -O2 -g -std=c++17 -fPIC -mfma $(FPFLAGS) -Wall -Wextra -Wno-unused-parameter -I$(ROOT)/include -I$(PKG)/host
-HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=gfx950 $(FPFLAGS) -fhip-fp32-correctly-rounded-divide-sqrt \
+HIPFLAGS := $(HIPDEFS) -O3 -std=c++17 -fPIC --offload-arch=gfx950 $(FPFLAGS) -fhip-fp32-correctly-rounded-divide-sqrt \
             -fno-gpu-flush-denormals-to-zero -mfma -Wall -Wno-unused-parameter -I$(ROOT)/include -I$(PKG)/csrc
 
 HOST_SRC := $(PKG)/host/scene_build.cpp $(PKG)/host/scene_io.cpp $(PKG)/host/host_capi.cpp
@@ -16,7 +16,7 @@ HOST_HDR := $(PKG)/host/jade_host.hpp $(ROOT)/include/jade_host_c.h $(ROOT)/incl
 HIP_SRC  := $(wildcard $(PKG)/csrc/*.hip)
 HIP_HDR  := $(wildcard $(PKG)/csrc/*.h) $(ROOT)/include/jade_rt.h $(ROOT)/include/jade_fpmath.h
 
-all: host hip oracle cli
+all: host hip hipvariants oracle cli
 
 host: $(LIBDIR)/libjade_host.so
 hip: $(LIBDIR)/libjade_hip.so
@@ -32,6 +32,14 @@ $(LIBDIR)/libjade_hip.so: $(HIP_SRC) $(HIP_HDR)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC)
 
+# test-only build: a 4-entry LDS stack forces the global-memory spill path of the
+# traversal stack on every scene (tests/test_gpu_parity.py::test_stack_spill_path)
+$(LIBDIR)/libjade_hip_stack4.so: $(HIP_SRC) $(HIP_HDR)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) -DJADE_LDS_STACK=4 $(HIPFLAGS) -shared -o $@ $(HIP_SRC)
+
+hipvariants: $(LIBDIR)/libjade_hip_stack4.so
+
 $(LIBDIR)/jade_render: $(PKG)/host/jade_render_cli.cpp $(LIBDIR)/libjade_host.so $(HOST_HDR)
 	$(CXX) $(CXXFLAGS) -o $@ $(PKG)/host/jade_render_cli.cpp -L$(LIBDIR) -ljade_host -ldl -Wl,-rpath,'$$ORIGIN'
 
@@ -39,4 +47,4 @@ clean:
 	rm -rf $(LIBDIR)
 	$(MAKE) -C $(ROOT)/oracle clean
 
-.PHONY: all host hip oracle cli clean
+.PHONY: all host hip hipvariants oracle cli clean

@@ -30,7 +30,12 @@
 #define JADE_MAX_LEAF 15
 #define JADE_INF_F 2147483647.0f /* #define INF, PathTrace.cu:23 */
 
-#define JADE_LDS_STACK 32 /* traversal stack entries kept in LDS per lane */
+#ifndef JADE_LDS_STACK
+#define JADE_LDS_STACK 24 /* traversal stack entries kept in LDS per lane: 24 KB/block -> 6 blocks/CU */
+#endif
+#ifndef JADE_TRIS_PER_STEP
+#define JADE_TRIS_PER_STEP 1 /* triangle tests per traversal unit (1 or 2); 2 costs 38 VGPRs = 2 waves/SIMD */
+#endif
 #define JADE_TRACE_BLOCK 256
 #define JADE_RECORD_BUDGET (72ll << 20) /* path records kept in flight per GPU (~250 B each) */
 
@@ -120,7 +125,9 @@ struct DevCounters {
 };
 #define JADE_TRACE_CHUNK 512 /* most rays a wave claims per queue atomic */
 #define JADE_REFILL_MIN 16    /* idle lanes in a wave that trigger a refill */
-#define JADE_STEPS_PER_CHECK 3 /* traversal units between two refill checks */
+#ifndef JADE_STEPS_PER_CHECK
+#define JADE_STEPS_PER_CHECK 1 /* traversal units between two refill checks (more costs 30 VGPRs) */
+#endif
 
 static __device__ __forceinline__ jvec3 ld3(const float* a, int npix, int p) {
   return jv(a[p], a[npix + p], a[2 * npix + p]);

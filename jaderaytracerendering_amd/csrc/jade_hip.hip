@@ -100,7 +100,10 @@ __global__ __launch_bounds__(256) void k_arm(PathState P, uint32_t target_spp, u
   }
 }
 
-__global__ __launch_bounds__(256) void k_shade(DevScene S, PathState P, RenderConst R, const int32_t* tile_ids,
+#ifndef JADE_SHADE_WAVES
+#define JADE_SHADE_WAVES 4 /* 128 VGPRs, no spill: +3 % over 3 waves/SIMD */
+#endif
+__global__ __launch_bounds__(256, JADE_SHADE_WAVES) void k_shade(DevScene S, PathState P, RenderConst R, const int32_t* tile_ids,
                                                uint32_t target_spp, const uint32_t* active_in, uint32_t n_active,
                                                uint32_t* active_out, uint32_t* queue, QueueCtl* qc, DevCounters* ctr) {
   __shared__ uint32_t sh_rays[4], sh_act[4], sh_base[2];
@@ -283,7 +286,10 @@ __global__ __launch_bounds__(256) void k_shade(DevScene S, PathState P, RenderCo
   }
 }
 
-__global__ __launch_bounds__(JADE_TRACE_BLOCK) void k_trace(DevScene S, PathState P, const uint32_t* queue, QueueCtl* qc,
+#ifndef JADE_TRACE_WAVES
+#define JADE_TRACE_WAVES 1
+#endif
+__global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(DevScene S, PathState P, const uint32_t* queue, QueueCtl* qc,
                                                            uint32_t* spill, DevCounters* ctr, uint32_t chunk) {
   __shared__ uint32_t lds_stack[JADE_LDS_STACK * JADE_TRACE_BLOCK];
   const int lane = threadIdx.x & 63;

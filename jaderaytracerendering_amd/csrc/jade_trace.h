@@ -159,7 +159,7 @@ static __device__ __forceinline__ bool ray_step(RayState& r, const DevScene& S, 
     // ---- up to two triangles of the current leaf (hitArray, PathTrace.cu:776-792),
     // tested in index order; both vertex records are requested before either is used
     const uint32_t i = r.tri_i;
-    const bool two = i + 1 < r.tri_n;
+    const bool two = JADE_TRIS_PER_STEP > 1 && i + 1 < r.tri_n;
     const uint32_t j = two ? i + 1 : i;
     const float4 a0 = S.tverts[3 * (size_t)i], b0 = S.tverts[3 * (size_t)i + 1], c0 = S.tverts[3 * (size_t)i + 2];
     const float4 a1 = S.tverts[3 * (size_t)j], b1 = S.tverts[3 * (size_t)j + 1], c1 = S.tverts[3 * (size_t)j + 2];

@@ -135,6 +135,32 @@ def test_many_samples_per_lane_match_oracle(oracle, hip):
     _assert_parity(*_render_both(oracle, hip, hs, p))
 
 
+def test_c5_deep_bvh_subset(oracle, hip):
+    """configs[4] scene: 873,634-triangle "dragon" stand-in, BVH depth 25 (> the 24 LDS stack levels)."""
+    hs, cfg = config_scene("C5")
+    assert hs.n_triangles == 20 * 209 * 209 + 14 and hs.bvh_depth > 24
+    p = B.params_from_config(cfg, spp=2)
+    p.width, p.height = 96, 54
+    _assert_parity(*_render_both(oracle, hip, hs, p))
+    o, d, skip = _random_rays(hs, 20000, 77)
+    with oracle.scene(hs) as so, hip.scene(hs) as sh:
+        i_o, t_o, p_o, st_o = so.trace_rays(o, d, skip)
+        i_h, t_h, p_h, st_h = sh.trace_rays(o, d, skip)
+    assert np.array_equal(i_o, i_h) and (st_o.nodes_visited, st_o.tris_tested) == (st_h.nodes_visited, st_h.tris_tested)
+
+
+def test_stack_spill_path(oracle):
+    """A build with a 4-entry LDS stack: every traversal deeper than 4 goes through the global spill area."""
+    import os
+    from jaderaytracerendering_amd.backend import Backend, _LIBDIR
+    be = Backend(os.path.join(_LIBDIR, "libjade_hip_stack4.so"))
+    for name, size, spp in (("tinyjade", 32, 4), ("C2", 48, 2)):
+        hs, cfg = config_scene(name)
+        p = B.params_from_config(cfg, spp=spp)
+        p.width = p.height = size
+        _assert_parity(*_render_both(oracle, be, hs, p))
+
+
 def _random_rays(hs, n, seed):
     rng = np.random.default_rng(seed)
     v = hs.vertices().reshape(-1, 3)

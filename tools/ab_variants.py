@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Development A/B: time one 256-spp step of C3 with several builds of libjade_hip*.so in ONE process
+(interleaved variants, cdna_hip_programming.md rule 24).  usage: ab_variants.py "" _A _B ..."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import jaderaytracerendering_amd as J  # noqa: E402
+from jaderaytracerendering_amd import _abi, backend as B  # noqa: E402
+
+hs, cfg = J.build_config("C3")
+scenes = {}
+for name in sys.argv[1:]:
+    be = B.Backend(os.path.join(ROOT, "jaderaytracerendering_amd", "lib", "libjade_hip%s.so" % name))
+    sc = be.scene(hs)
+    sc.begin(B.make_params(1920, 1080, 256, list(cfg.eye), list(cfg.camera)))
+    sc.step(256)
+    scenes[name or "base"] = sc
+best = {}
+for rnd in range(2):
+    for name, sc in scenes.items():
+        st = _abi.Stats()
+        t = time.perf_counter()
+        sc.step(256, st)
+        dt = time.perf_counter() - t
+        r = (st.rays / dt / 1e6, st.trace_ms, st.kernel_ms)
+        if name not in best or r[0] > best[name][0]:
+            best[name] = r
+for name, r in best.items():
+    print("%-6s Mray/s %.0f  trace_ms %.0f  kernel_ms %.0f" % ((name,) + r), flush=True)
