@@ -125,6 +125,15 @@ struct DevCounters {
 };
 #define JADE_TRACE_CHUNK 512 /* most rays a wave claims per queue atomic */
 #define JADE_REFILL_MIN 16    /* idle lanes in a wave that trigger a refill */
+#ifndef JADE_PHASED
+#define JADE_PHASED 0       /* 1: run one kind of traversal unit per wave iteration (measured slower: 2067 vs 2214 Mray/s) */
+#endif
+#ifndef JADE_COST_NODE
+#define JADE_COST_NODE 60   /* relative issue cost of a node visit ... */
+#endif
+#ifndef JADE_COST_TRI
+#define JADE_COST_TRI 130   /* ... and of a triangle test */
+#endif
 #ifndef JADE_STEPS_PER_CHECK
 #define JADE_STEPS_PER_CHECK 1 /* traversal units between two refill checks (more costs 30 VGPRs) */
 #endif

@@ -342,17 +342,34 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
       lbase += take;
     }
     if (n_idle == 64 && queue_empty) break;  // nothing in flight, nothing left to claim
-    // ---- a few traversal units per active lane between refill checks
-#pragma unroll 1
-    for (int it = 0; it < JADE_STEPS_PER_CHECK; ++it) {
-      if (active && !ray_step(r, S, stk, V, T)) {
-        P.hit[(size_t)my_k * npix + my_p] = r.best_index;
+    // ---- one traversal unit per lane, ONE kind per iteration: a node visit costs
+    // about JADE_COST_NODE instructions and a triangle test JADE_COST_TRI, and running
+    // both kinds back to back with half the lanes masked in each wastes issue slots, so
+    // the wave runs whichever kind advances more lanes per instruction; the others wait
+    // (they become the majority soon enough: no lane can starve).
+    bool fin = false;
+#if JADE_PHASED
+    {
+      const bool wt = active && ray_wants_tri(r);
+      const int nt = __popcll(__ballot(wt)), nn = __popcll(__ballot(active && !wt));
+      if (JADE_COST_TRI * nn >= JADE_COST_NODE * nt) {
+        if (active && !wt) fin = !ray_step_node(r, S, stk, V);
+      } else {
+        if (wt) fin = !ray_step_tri(r, S, stk, T);
+      }
+    }
+#else
+    if (active) fin = !ray_step(r, S, stk, V, T);
+#endif
+    if (fin) {
+      P.hit[(size_t)my_k * npix + my_p] = r.best_index;
+      if (r.best_index >= 0) {  // the hit point of a miss is never read
         float* hb = P.hpt + (size_t)my_k * npix + my_p;
         hb[0] = r.best_point.x;
         hb[plane] = r.best_point.y;
         hb[2 * plane] = r.best_point.z;
-        active = false;
       }
+      active = false;
     }
   }
   unsigned long long sv = wave_sum_u32(V), stt = wave_sum_u32(T);

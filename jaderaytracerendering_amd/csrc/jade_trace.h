@@ -153,19 +153,52 @@ static __device__ __forceinline__ void ray_goto(RayState& r, uint32_t ref) {
   }
 }
 
-// Returns false when the ray has finished.
-static __device__ __forceinline__ bool ray_step(RayState& r, const DevScene& S, const LdsStack& stk, uint32_t& V, uint32_t& T) {
-  if (r.tri_i < r.tri_n) {
+// Development ablations (cdna_hip_programming.md rule 17): JADE_ABLATE_* repeat a
+// piece of work without changing any result, to price that piece.  Off in product builds.
+#ifndef JADE_ABLATE_TRI
+#define JADE_ABLATE_TRI 0
+#endif
+#ifndef JADE_ABLATE_SLAB
+#define JADE_ABLATE_SLAB 0
+#endif
+#ifndef JADE_ABLATE_LOAD
+#define JADE_ABLATE_LOAD 0
+#endif
+
+// One traversal unit, split by kind so that a wave can run only one kind per
+// iteration (see k_trace).  Both return false when the ray has finished.
+static __device__ __forceinline__ bool ray_wants_tri(const RayState& r) { return r.tri_i < r.tri_n; }
+
+static __device__ __forceinline__ bool ray_step_tri(RayState& r, const DevScene& S, const LdsStack& stk, uint32_t& T) {
     // ---- up to two triangles of the current leaf (hitArray, PathTrace.cu:776-792),
     // tested in index order; both vertex records are requested before either is used
     const uint32_t i = r.tri_i;
     const bool two = JADE_TRIS_PER_STEP > 1 && i + 1 < r.tri_n;
     const uint32_t j = two ? i + 1 : i;
-    const float4 a0 = S.tverts[3 * (size_t)i], b0 = S.tverts[3 * (size_t)i + 1], c0 = S.tverts[3 * (size_t)i + 2];
-    const float4 a1 = S.tverts[3 * (size_t)j], b1 = S.tverts[3 * (size_t)j + 1], c1 = S.tverts[3 * (size_t)j + 2];
+    // 32-bit byte offsets from a scalar base (n_tris < 2^27: 48 B * i fits): saddr + voffset loads
+    const char* tb = reinterpret_cast<const char*>(S.tverts);
+    const float4* t0 = reinterpret_cast<const float4*>(tb + i * 48u);
+    const float4* t1 = reinterpret_cast<const float4*>(tb + j * 48u);
+    const float4 a0 = t0[0], b0 = t0[1], c0 = t0[2];
+    const float4 a1 = t1[0], b1 = t1[1], c1 = t1[2];
     r.tri_i = j + 1;
     float dist;
     jvec3 P;
+#if JADE_ABLATE_TRI
+    {
+      float d2; jvec3 P2;
+      jvec3 o2 = jv(r.o.x + 1e-30f, r.o.y, r.o.z);
+      bool h2 = tri_test(jv(a0.x, a0.y, a0.z), jv(b0.x, b0.y, b0.z), jv(c0.x, c0.y, c0.z), o2, r.dn, &d2, &P2);
+      asm volatile("" ::"v"(h2 ? d2 + P2.x : 0.0f));
+    }
+#endif
+#if JADE_ABLATE_LOAD
+    {
+      const float4 x = S.tverts[3 * (size_t)i];
+      const float4 y = S.tverts[3 * (size_t)(__float_as_uint(x.w) & 1u)];  // dependent on the first
+      asm volatile("" ::"v"(y.x));
+    }
+#endif
     if ((int32_t)i != r.skip) {
       T += 1;
       if (tri_test(jv(a0.x, a0.y, a0.z), jv(b0.x, b0.y, b0.z), jv(c0.x, c0.y, c0.z), r.o, r.dn, &dist, &P) && dist < r.best_dist) {
@@ -184,13 +217,28 @@ static __device__ __forceinline__ bool ray_step(RayState& r, const DevScene& S, 
     }
     if (r.tri_i < r.tri_n) return true;
     return ray_pop(r, stk);
-  }
+}
+
+static __device__ __forceinline__ bool ray_step_node(RayState& r, const DevScene& S, const LdsStack& stk, uint32_t& V) {
   if (r.cur & JADE_REF_LEAF) return ray_pop(r, stk);  // empty leaf (cannot happen for a valid BVH)
   // ---- one internal node
-  const float4* nd = S.nodes + 4 * (size_t)r.cur;
+  const float4* nd = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.nodes) + r.cur * 64u);
   const float4 a = nd[0], b = nd[1], c = nd[2];
   const uint4 rf = *reinterpret_cast<const uint4*>(nd + 3);
   float d1 = -1.0f, d2 = -1.0f;
+#if JADE_ABLATE_SLAB
+  {
+    jvec3 o2 = jv(r.o.x + 1e-30f, r.o.y, r.o.z);
+    float e1 = slab(o2, r.inv, a.x, a.y, a.z, a.w, b.x, b.y, r.exact), e2 = slab(o2, r.inv, b.z, b.w, c.x, c.y, c.z, c.w, r.exact);
+    asm volatile("" ::"v"(e1 + e2));
+  }
+#endif
+#if JADE_ABLATE_LOAD
+  {
+    const float4 y = S.nodes[4 * (size_t)(rf.x & 1u)];  // dependent on this node's record
+    asm volatile("" ::"v"(y.x));
+  }
+#endif
   if (rf.x != JADE_REF_NONE) {
     V += 1;
     d1 = slab(r.o, r.inv, a.x, a.y, a.z, a.w, b.x, b.y, r.exact);
@@ -218,4 +266,10 @@ static __device__ __forceinline__ bool ray_step(RayState& r, const DevScene& S, 
     return true;
   }
   return ray_pop(r, stk);
+}
+
+// Returns false when the ray has finished.
+static __device__ __forceinline__ bool ray_step(RayState& r, const DevScene& S, const LdsStack& stk, uint32_t& V, uint32_t& T) {
+  if (ray_wants_tri(r)) return ray_step_tri(r, S, stk, T);
+  return ray_step_node(r, S, stk, V);
 }
