@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL) for real runs; gloo rehearses the multi-rank flow with every rank on one GPU")
     ap.add_argument("--virtual-ranks", type=int, default=0,
                     help="development: render rank 0's share of a V-GPU run on this one GPU (partition and spp as at N=V)")
     ap.add_argument("--cpu-spp", type=int, default=8, help="oracle sample: spp over the full frame")
@@ -65,11 +67,18 @@ def main():
     hip = J.hip()  # raises if the HIP extension is missing: no fallback
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+    rehearsal = args.dist_backend == "gloo"
+    if rehearsal:
+        local_rank = 0  # every rank shares GPU 0; collectives go through host memory
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if rehearsal else dev  # where collective payloads live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     t0 = time.time()
     hs, cfg = J.build_config(args.config)
@@ -107,7 +116,7 @@ def main():
     barrier()
     g0 = time.perf_counter()
     scene.resolve_tiles_device(tiles.data_ptr(), torch.cuda.current_stream().cuda_stream)
-    frame = D.gather_framebuffer(tiles, width, height) if world > 1 else None
+    frame = D.gather_framebuffer(tiles.to(cdev), width, height) if world > 1 else None
     barrier()
     gather_ms = (time.perf_counter() - g0) * 1e3
     if world == 1 and part_world == 1:
@@ -117,8 +126,8 @@ def main():
         frame_ok = bool(torch.isfinite(frame).all().item()) and tuple(frame.shape) == (height, width, 3)
 
     vals = torch.tensor([float(st.rays_primary + st.rays_secondary), float(st.nodes_visited), float(st.tris_tested),
-                         st.trace_ms, float(st.trace_launches), float(st.samples)], dtype=torch.float64, device=dev)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+                         st.trace_ms, float(st.trace_launches), float(st.samples)], dtype=torch.float64, device=cdev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(vals, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -158,6 +167,7 @@ def main():
                 "bvh_nodes": hs.n_nodes, "bvh_depth": hs.bvh_depth, "parallelism": f"tiles{world}",
             },
             "virtual_ranks": part_world if part_world != world else None,
+            "rehearsal_all_ranks_on_one_gpu": True if rehearsal else None,
             "rays": rays_all,
             "samples": float(vals[5].item()),
             "gather_ms": gather_ms,

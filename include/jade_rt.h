@@ -183,6 +183,18 @@ int jade_render_begin(jade_scene* scene, const jade_render_params* params);
 int jade_render_step(jade_scene* scene, int32_t spp, jade_stats* stats_accum);
 int jade_render_resolve(jade_scene* scene, float* out_rgb, uint8_t* out_bgr8);
 
+/* Resolve with a choice of tone operator for out_bgr8 (out_rgb is always the
+ * linear mean):
+ *   JADE_TONEMAP_ACES      ACESToneMapping, PathTrace.cu:680-682 (what the CUDA
+ *                          program writes; jade_render_resolve uses this)
+ *   JADE_TONEMAP_REINHARD  toneMapping(c, limit) = c / (1 + luminance/limit),
+ *                          PathTrace.cu:669-672 == shaders/pass3.fsh:8-18, the
+ *                          GL preview's post pass (limit 1.5 there)
+ * followed in both cases by gamma 1/2.2, x255, clamp, BGR (PathTrace.cu:1464-1473). */
+#define JADE_TONEMAP_ACES 0
+#define JADE_TONEMAP_REINHARD 1
+int jade_render_resolve_ex(jade_scene* scene, int tonemap, float limit, float* out_rgb, uint8_t* out_bgr8);
+
 /* Device-resident resolve for multi-GPU gathers (HIP backend only; the oracle
  * returns JADE_ERR_UNSUPPORTED).  Writes this rank's tiles compactly into
  * device memory: tile t (t-th owned tile in increasing row-major id) occupies

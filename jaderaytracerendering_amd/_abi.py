@@ -11,6 +11,7 @@ JADE_OK, JADE_ERR_INVALID, JADE_ERR_DEVICE, JADE_ERR_NOMEM, JADE_ERR_UNSUPPORTED
 DIFFUSE, MIRROR = 0, 1
 NO_REFRACT, SUB_SURFACE, DIR_REFRACT = 0, 1, 2
 TILE_SIZE = 16
+TONEMAP_ACES, TONEMAP_REINHARD = 0, 1
 
 f3 = C.c_float * 3
 f16 = C.c_float * 16
@@ -101,6 +102,7 @@ RT_SYMBOLS = {
     "jade_render_begin": (C.c_int, [C.c_void_p, C.POINTER(RenderParams)]),
     "jade_render_step": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(Stats)]),
     "jade_render_resolve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "jade_render_resolve_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "jade_render_resolve_tiles_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "jade_owned_tile_count": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "jade_trace_rays": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

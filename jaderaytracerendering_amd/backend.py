@@ -110,12 +110,16 @@ class Scene:
         self.backend.check(self.backend.lib.jade_render_step(self._h, int(spp), C.byref(st)))
         return st
 
-    def resolve(self, want_rgb=True, want_bgr8=True):
+    def resolve(self, want_rgb=True, want_bgr8=True, tonemap=None, limit=1.5):
+        """tonemap None/ACES: PathTrace.cu:680-682; _abi.TONEMAP_REINHARD: the preview's pass3.fsh operator."""
         h, w = self._params.height, self._params.width
         rgb = np.zeros((h, w, 3), np.float32) if want_rgb else None
         bgr = np.zeros((h, w, 3), np.uint8) if want_bgr8 else None
-        self.backend.check(self.backend.lib.jade_render_resolve(self._h, rgb.ctypes.data if want_rgb else None,
-                                                                bgr.ctypes.data if want_bgr8 else None))
+        pr, pb = (rgb.ctypes.data if want_rgb else None), (bgr.ctypes.data if want_bgr8 else None)
+        if tonemap is None:
+            self.backend.check(self.backend.lib.jade_render_resolve(self._h, pr, pb))
+        else:
+            self.backend.check(self.backend.lib.jade_render_resolve_ex(self._h, int(tonemap), float(limit), pr, pb))
         return rgb, bgr
 
     def resolve_tiles_device(self, dev_ptr, stream=0):

@@ -381,7 +381,7 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
 }
 
 // ACESToneMapping + gamma + BGR pack, PathTrace.cu:680-682, 1457-1473.
-__global__ void k_resolve(PathState P, float inv_spp, float* out_rgb, uint8_t* out_bgr) {
+__global__ void k_resolve(PathState P, float inv_spp, int tonemap, float limit, float* out_rgb, uint8_t* out_bgr) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;  // owned pixel
   if (p >= P.npx) return;
   bool valid = (P.stage[p] & 255u) != ST_INVALID;
@@ -400,12 +400,21 @@ __global__ void k_resolve(PathState P, float inv_spp, float* out_rgb, uint8_t* o
   }
   if (out_bgr) {
     float v[3] = {m.x, m.y, m.z};
+    float rein = 1.0f;
+    if (tonemap == JADE_TONEMAP_REINHARD) {  // toneMapping(c, limit), PathTrace.cu:669-672 / pass3.fsh:8-18
+      float luminance = (float)(0.3 * (double)m.x + 0.6 * (double)m.y + 0.1 * (double)m.z);
+      rein = (float)(1.0 / (1.0 + (double)(luminance / limit)));
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       float x = v[k];
-      float num = x * (x * 2.51f + 0.03f);
-      float den = x * (x * 2.43f + 0.59f) + 0.14f;
-      x = num / den;
+      if (tonemap == JADE_TONEMAP_REINHARD) {
+        x = x * rein;
+      } else {
+        float num = x * (x * 2.51f + 0.03f);
+        float den = x * (x * 2.43f + 0.59f) + 0.14f;
+        x = num / den;
+      }
       x = jade_powf(x, (float)(1.0 / 2.2));
       x = x * 255.0f;
       x = x > 255 ? 255 : x;
@@ -850,24 +859,29 @@ int jade_render_step(jade_scene* s, int32_t spp, jade_stats* st) {
   return JADE_OK;
 }
 
-static int resolve_to(jade_scene* s, float* dev_rgb, uint8_t* dev_bgr, hipStream_t stream) {
+static int resolve_to(jade_scene* s, int tonemap, float limit, float* dev_rgb, uint8_t* dev_bgr, hipStream_t stream) {
   const int npix = s->ps.npx;
   if (npix == 0) return JADE_OK;
   float inv = (float)(1.0 / (double)s->spp_done);  // vec3(1.0 / spp), PathTrace.cu:1457
-  hipLaunchKernelGGL(k_resolve, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream, s->ps, inv, dev_rgb, dev_bgr);
+  hipLaunchKernelGGL(k_resolve, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream, s->ps, inv, tonemap, limit, dev_rgb, dev_bgr);
   HIP_TRY(hipGetLastError());
   return JADE_OK;
 }
 
 int jade_render_resolve(jade_scene* s, float* out_rgb, uint8_t* out_bgr8) {
+  return jade_render_resolve_ex(s, JADE_TONEMAP_ACES, 0.0f, out_rgb, out_bgr8);
+}
+
+int jade_render_resolve_ex(jade_scene* s, int tonemap, float limit, float* out_rgb, uint8_t* out_bgr8) {
   if (!s || !s->have_rp) return fail(JADE_ERR_INVALID, "jade_render_begin not called");
+  if (tonemap != JADE_TONEMAP_ACES && tonemap != JADE_TONEMAP_REINHARD) return fail(JADE_ERR_INVALID, "unknown tone operator");
   if (s->spp_done <= 0) return fail(JADE_ERR_INVALID, "no samples rendered yet");
   HIP_TRY(hipSetDevice(s->device));
   const int npix = s->ps.npx;
   if (npix == 0) return JADE_OK;
   if (out_rgb) HIP_TRY(s->b_out_rgb.alloc((size_t)npix * 12));
   if (out_bgr8) HIP_TRY(s->b_out_bgr.alloc((size_t)npix * 3));
-  int rc = resolve_to(s, out_rgb ? s->b_out_rgb.as<float>() : nullptr, out_bgr8 ? s->b_out_bgr.as<uint8_t>() : nullptr, s->stream);
+  int rc = resolve_to(s, tonemap, limit, out_rgb ? s->b_out_rgb.as<float>() : nullptr, out_bgr8 ? s->b_out_bgr.as<uint8_t>() : nullptr, s->stream);
   if (rc) return rc;
   std::vector<float> hrgb;
   std::vector<uint8_t> hbgr;
@@ -899,7 +913,7 @@ int jade_render_resolve_tiles_device(jade_scene* s, float* dev_tiles, void* stre
   if (s->spp_done <= 0) return fail(JADE_ERR_INVALID, "no samples rendered yet");
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipStreamSynchronize(s->stream));
-  return resolve_to(s, dev_tiles, nullptr, (hipStream_t)stream);
+  return resolve_to(s, JADE_TONEMAP_ACES, 0.0f, dev_tiles, nullptr, (hipStream_t)stream);
 }
 
 int jade_render(jade_scene* s, const jade_render_params* rp, float* out_rgb, uint8_t* out_bgr8, jade_stats* st) {

@@ -791,14 +791,23 @@ static jvec3 render_sample(const jade_scene* s, const jade_render_params* rp, in
   return color;
 }
 
-/* PathTrace.cu:680-682, 1461-1473 */
-static void tonemap_pack(jvec3 c, uint8_t* bgr) {
+/* PathTrace.cu:680-682 (ACES) or :669-672 == pass3.fsh:8-18 (toneMapping), then :1461-1473 */
+static void tonemap_pack(jvec3 c, int mode, float limit, uint8_t* bgr) {
   float v[3] = {c.x, c.y, c.z};
+  float rein = 1.0f;
+  if (mode == JADE_TONEMAP_REINHARD) {
+    float luminance = (float)(0.3 * (double)c.x + 0.6 * (double)c.y + 0.1 * (double)c.z);
+    rein = (float)(1.0 / (1.0 + (double)(luminance / limit)));
+  }
   for (int k = 0; k < 3; ++k) {
     float x = v[k];
-    float num = x * (x * 2.51f + 0.03f);
-    float den = x * (x * 2.43f + 0.59f) + 0.14f;
-    x = num / den;
+    if (mode == JADE_TONEMAP_REINHARD) {
+      x = x * rein;
+    } else {
+      float num = x * (x * 2.51f + 0.03f);
+      float den = x * (x * 2.43f + 0.59f) + 0.14f;
+      x = num / den;
+    }
     x = jade_powf(x, (float)(1.0 / 2.2));
     x = x * 255.0f;
     x = x > 255 ? 255 : x;
@@ -1007,7 +1016,12 @@ int jade_render_step(jade_scene* s, int32_t spp, jade_stats* st) {
 }
 
 int jade_render_resolve(jade_scene* s, float* out_rgb, uint8_t* out_bgr8) {
+  return jade_render_resolve_ex(s, JADE_TONEMAP_ACES, 0.0f, out_rgb, out_bgr8);
+}
+
+int jade_render_resolve_ex(jade_scene* s, int tonemap, float limit, float* out_rgb, uint8_t* out_bgr8) {
   if (!s || !s->have_rp) return fail(JADE_ERR_INVALID, "jade_render_begin not called");
+  if (tonemap != JADE_TONEMAP_ACES && tonemap != JADE_TONEMAP_REINHARD) return fail(JADE_ERR_INVALID, "unknown tone operator");
   const jade_render_params* rp = &s->rp;
   /* final_result * vec3(1.0 / spp), PathTrace.cu:1457 */
   float inv = (float)(1.0 / (double)s->spp_done);
@@ -1023,7 +1037,7 @@ int jade_render_resolve(jade_scene* s, float* out_rgb, uint8_t* out_bgr8) {
       }
       jvec3 m = jv(tot.x * inv, tot.y * inv, tot.z * inv);
       if (out_rgb) { out_rgb[3 * pi] = m.x; out_rgb[3 * pi + 1] = m.y; out_rgb[3 * pi + 2] = m.z; }
-      if (out_bgr8) tonemap_pack(m, out_bgr8 + 3 * pi);
+      if (out_bgr8) tonemap_pack(m, tonemap, limit, out_bgr8 + 3 * pi);
     }
   return JADE_OK;
 }

@@ -161,6 +161,23 @@ def test_stack_spill_path(oracle):
         _assert_parity(*_render_both(oracle, be, hs, p))
 
 
+def test_preview_tone_operator(oracle, hip):
+    """jade_render_resolve_ex with the GL preview's operator (pass3.fsh:8-18 == PathTrace.cu:669-672)."""
+    from jaderaytracerendering_amd import _abi
+    hs, cfg = config_scene("tinyjade")
+    p = B.params_from_config(cfg, spp=8)
+    with oracle.scene(hs) as so, hip.scene(hs) as sh:
+        outs = []
+        for sc in (so, sh):
+            sc.begin(p)
+            sc.step(8)
+            outs.append((sc.resolve(tonemap=_abi.TONEMAP_REINHARD, limit=1.5), sc.resolve()))
+    (ro, rh) = outs
+    assert np.abs(ro[0][1].astype(int) - rh[0][1].astype(int)).max() <= 1
+    assert (ro[0][1] != ro[1][1]).mean() > 0.2          # a genuinely different curve from ACES
+    assert np.array_equal(ro[0][0], ro[1][0])           # the linear mean is the same either way
+
+
 def _random_rays(hs, n, seed):
     rng = np.random.default_rng(seed)
     v = hs.vertices().reshape(-1, 3)

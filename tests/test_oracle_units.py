@@ -174,3 +174,21 @@ def test_empty_and_degenerate_inputs(oracle):
         q.width = q.height = 1
         rgb, _, st = sc.render(q)
         assert st.samples == 0 and (rgb == 0).all()
+
+
+def test_reinhard_preview_operator_closed_form(oracle):
+    """toneMapping(c, 1.5) = c / (1 + (0.3r + 0.6g + 0.1b)/1.5), then gamma 1/2.2 (pass3.fsh:8-18)."""
+    from jaderaytracerendering_amd import _abi
+    light = H.material(emissive=(1.5, 1.0, 0.5), brdf=(0.3, 0.3, 0.3))
+    hs = _scene([[[-50, -50, 0], [50, -50, 0], [0, 80, 0]]], [light], env=(0, 0, 0))
+    p = _cam_down_z(4, 1)
+    with oracle.scene(hs) as sc:
+        sc.begin(p)
+        sc.step(1)
+        rgb, bgr = sc.resolve(tonemap=_abi.TONEMAP_REINHARD, limit=1.5)
+        with pytest.raises(B.JadeError):
+            sc.resolve(tonemap=7)
+    c = np.array([3.0, 2.0, 1.0])                       # 2 x emissive on a primary light hit
+    t = c / (1 + (0.3 * c[0] + 0.6 * c[1] + 0.1 * c[2]) / 1.5)
+    want = np.floor(np.minimum(255 * t ** (1 / 2.2), 255))[::-1]
+    assert np.array_equal(rgb[0, 0], np.float32([3, 2, 1])) and np.abs(bgr[0, 0].astype(int) - want).max() <= 1
