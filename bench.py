@@ -8,7 +8,8 @@ Workload (BASELINE.json configs[2]/[3]): the 70k-triangle jade statue scene at
 1920x1080.  A "step" is one pass of the hot path adding `spp_per_step` samples to
 every pixel this rank owns; the per-pixel RNG streams and radiance sums stay on
 the GPU between steps, so K steps are K*spp_per_step samples of the same
-4096-spp render, not K restarts.  Multi-GPU: the image's 16x16 tiles are dealt
+render, not K restarts; the defaults (4 steps x 1024 spp) are exactly the
+4096-spp render BASELINE.json names.  Multi-GPU: the image's 16x16 tiles are dealt
 round-robin to the ranks and the samples per step scale with N, so per-GPU work
 per step is constant ("weak"); after the timed steps the framebuffer is
 collected with ONE gather (RCCL), timed separately as gather_ms.
@@ -39,7 +40,7 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="C3")
-    ap.add_argument("--spp-per-step", type=int, default=256, help="samples per pixel per step at N = 1")
+    ap.add_argument("--spp-per-step", type=int, default=1024, help="samples per pixel per step at N = 1")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -66,10 +66,19 @@ struct DevScene {
 // not depend on rpp.  `nslots` = n_emit + 2 ray slots per record: [0, n_emit)
 // shadow rays, n_emit = environment-visibility ray, n_emit + 1 = indirect
 // ray; single-ray stages use slot 0.
+//
+// Which pixel a record works on rotates: its n-th sample inside a block of
+// JADE_SAMPLE_LANES samples goes to pixel (home + n * stride) % npx.  Every
+// (pixel, sample) is still covered exactly once (for fixed n the map is a
+// bijection on pixels), but the few pixels whose samples are 10x more expensive
+// (the statue) no longer queue all their samples on the same records.  Inside
+// one block each (pixel, lane) partial sum is touched by exactly one record, so
+// the host runs a render block by block and the result stays bit-identical.
 struct PathState {
   int32_t npix;         // number of path records (= npx * rpp)
   int32_t npx;          // owned pixels (tile-padded)
   int32_t rpp;          // records per pixel
+  int32_t stride;       // pixel rotation per sample (see above)
   int32_t nslots;
   uint32_t* rng;        // Wang-hash state of the sample in flight
   uint32_t* done;       // samples this record has finished

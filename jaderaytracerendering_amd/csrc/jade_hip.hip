@@ -55,19 +55,36 @@ static __device__ __forceinline__ unsigned long long wave_sum_u32(uint32_t v) {
   return x;  // valid in lane 0
 }
 
+// Record p has finished `done` samples: which sample comes next and for which owned pixel.
+struct NextSample {
+  uint32_t sidx;  // global sample index (jade_rt.h)
+  int pixel;      // owned-pixel index it belongs to
+};
+static __device__ __forceinline__ NextSample next_sample(const PathState& P, int p, uint32_t done) {
+  const uint32_t m = (uint32_t)p / (uint32_t)P.npx;
+  const uint32_t home = (uint32_t)p - m * (uint32_t)P.npx;
+  const uint32_t per = JADE_SAMPLE_LANES / (uint32_t)P.rpp;  // samples per record per block
+  const uint32_t blk = done / per, n = done - blk * per;
+  NextSample r;
+  r.sidx = JADE_SAMPLE_LANES * blk + m + (uint32_t)P.rpp * n;
+  r.pixel = (int)(((unsigned long long)home + (unsigned long long)n * (uint32_t)P.stride) % (uint32_t)P.npx);
+  return r;
+}
+static __device__ __forceinline__ bool pixel_xy(const RenderConst& R, const int32_t* tile_ids, int pixel, int* x, int* y) {
+  int t = pixel >> 8, l = pixel & 255;
+  int tid = tile_ids[t];
+  *x = (tid % R.tiles_x) * JADE_TILE_SIZE + (l & 15);
+  *y = (tid / R.tiles_x) * JADE_TILE_SIZE + (l >> 4);
+  return *x < R.width && *y < R.height;
+}
+
 __global__ void k_selftest(QueueCtl* q, float one) { q->fp_bad = (uint32_t)jade_fp_selftest(one); }
 
-__global__ void k_init(PathState P, RenderConst R, const int32_t* tile_ids) {
+__global__ void k_init(PathState P) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P.npix) return;
-  int pix = p % P.npx;
-  int t = pix >> 8, l = pix & 255;
-  int tid = tile_ids[t];
-  int x = (tid % R.tiles_x) * JADE_TILE_SIZE + (l & 15);
-  int y = (tid / R.tiles_x) * JADE_TILE_SIZE + (l >> 4);
-  bool valid = x < R.width && y < R.height;
   P.done[p] = 0;
-  P.stage[p] = valid ? ST_IDLE : ST_INVALID;
+  P.stage[p] = ST_IDLE;
 }
 
 // Lists every record that has work in this step (samples left to start, or a
@@ -77,11 +94,8 @@ __global__ __launch_bounds__(256) void k_arm(PathState P, uint32_t target_spp, u
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   bool want = false;
   if (p < P.npix) {
-    const uint32_t word = P.stage[p], st = word & 255u;
-    if (st != ST_INVALID) {
-      const uint32_t lane_m = (uint32_t)p / (uint32_t)P.npx;
-      want = st != ST_IDLE || lane_m + (uint32_t)P.rpp * P.done[p] < target_spp;
-    }
+    const uint32_t st = P.stage[p] & 255u;
+    want = st != ST_IDLE || next_sample(P, p, P.done[p]).sidx < target_spp;
   }
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const unsigned long long m = __ballot(want);
@@ -178,11 +192,10 @@ __global__ __launch_bounds__(256, JADE_SHADE_WAVES) void k_shade(DevScene S, Pat
     for (;;) {
       if (finished) {
         // final_result = final_result + color (PathTrace.cu:1454), into the partial sum of
-        // this sample's lane: only this record ever touches it
+        // this sample's (pixel, lane): only this record touches it in this block
         {
-          const uint32_t m = (uint32_t)p / (uint32_t)P.npx;
-          const uint32_t vl = (m + (uint32_t)P.rpp * done) % JADE_SAMPLE_LANES;
-          const int si = (int)(vl * (uint32_t)P.npx) + (p - (int)m * P.npx);
+          const NextSample cs = next_sample(P, p, done);  // the sample that just ended
+          const int si = (int)((cs.sidx % JADE_SAMPLE_LANES) * (uint32_t)P.npx) + cs.pixel;
           const int sn = JADE_SAMPLE_LANES * P.npx;
           st3(P.sum, sn, si, jv_add(ld3(P.sum, sn, si), color));
         }
@@ -201,17 +214,16 @@ __global__ __launch_bounds__(256, JADE_SHADE_WAVES) void k_shade(DevScene S, Pat
         continue;
       }
       if (st == ST_IDLE) {
-        // this record's samples are m, m + rpp, ...: `done` of them so far
-        const uint32_t lane_m = (uint32_t)p / (uint32_t)P.npx;
-        const uint32_t sidx = lane_m + (uint32_t)P.rpp * done;
-        if (sidx >= target_spp) break;
+        // next sample of this record; samples of out-of-image pixels (edge tiles) are skipped
+        int x, y;
+        NextSample ns = next_sample(P, p, done);
+        while (ns.sidx < target_spp && !pixel_xy(R, tile_ids, ns.pixel, &x, &y)) {
+          done += 1;
+          ns = next_sample(P, p, done);
+        }
+        if (ns.sidx >= target_spp) break;
         // camera ray, PathTrace.cu:1428-1437
-        int pixi = p - (int)lane_m * P.npx;
-        int t = pixi >> 8, l = pixi & 255;
-        int tid = tile_ids[t];
-        int x = (tid % R.tiles_x) * JADE_TILE_SIZE + (l & 15);
-        int y = (tid / R.tiles_x) * JADE_TILE_SIZE + (l >> 4);
-        c.rng = jade_rng_seed((uint32_t)x, (uint32_t)y, R.frame + sidx);
+        c.rng = jade_rng_seed((uint32_t)x, (uint32_t)y, R.frame + ns.sidx);
         float fx = (float)x + jade_rand(&c.rng);
         double lo = -1.0 + R.two_over_w * ((double)fx - 0.5);
         float left_offset = (float)(lo * R.aspect);
@@ -381,10 +393,12 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
 }
 
 // ACESToneMapping + gamma + BGR pack, PathTrace.cu:680-682, 1457-1473.
-__global__ void k_resolve(PathState P, float inv_spp, int tonemap, float limit, float* out_rgb, uint8_t* out_bgr) {
+__global__ void k_resolve(PathState P, RenderConst R, const int32_t* tile_ids, float inv_spp, int tonemap, float limit,
+                          float* out_rgb, uint8_t* out_bgr) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;  // owned pixel
   if (p >= P.npx) return;
-  bool valid = (P.stage[p] & 255u) != ST_INVALID;
+  int px_, py_;
+  bool valid = pixel_xy(R, tile_ids, p, &px_, &py_);
   jvec3 m = jv(0, 0, 0);
   if (valid) {
     // add the JADE_SAMPLE_LANES partial sums in lane order (jade_rt.h)
@@ -673,6 +687,14 @@ static int setup_state(jade_scene* s, int npx, int rpp, int nslots) {
   P.npix = npix;
   P.npx = npx;
   P.rpp = rpp;
+  {
+    // Pixel rotation is OFF by default: measured on C3 it cuts the passes per 256-sample block
+    // from 172 to 142 but de-synchronised records lose coalescing and ray coherence in the
+    // heavy passes (2155 vs 2229 Mray/s).  JADE_PIXEL_ROTATE=1 turns it on for experiments.
+    const int per = JADE_SAMPLE_LANES / rpp;
+    const char* e = getenv("JADE_PIXEL_ROTATE");
+    P.stride = (e && atoi(e) > 0 && per > 1) ? (npx / per) | 1 : 0;
+  }
   P.nslots = nslots;
   P.rng = b + o_rng; P.done = b + o_done; P.stage = b + o_stage;
   P.sum = (float*)(b + o_sum); P.thr = (float*)(b + o_thr); P.acc = (float*)(b + o_acc); P.le = (float*)(b + o_le);
@@ -724,7 +746,7 @@ int jade_render_begin(jade_scene* s, const jade_render_params* rp) {
   if (rc) return rc;
   HIP_TRY(upload(s->b_tiles, s->tile_ids.data(), s->tile_ids.size()));
   HIP_TRY(hipMemsetAsync(s->b_ctr.p, 0, sizeof(DevCounters) * JADE_CTR_SHARDS, s->stream));
-  hipLaunchKernelGGL(k_init, dim3((unsigned)((npix64 + 255) / 256)), dim3(256), 0, s->stream, s->ps, s->rc, s->b_tiles.as<int32_t>());
+  hipLaunchKernelGGL(k_init, dim3((unsigned)((npix64 + 255) / 256)), dim3(256), 0, s->stream, s->ps);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s->stream));
   s->have_rp = true;
@@ -841,8 +863,18 @@ int jade_render_step(jade_scene* s, int32_t spp, jade_stats* st) {
   HIP_TRY(hipMemsetAsync(s->b_ctr.p, 0, sizeof(DevCounters) * JADE_CTR_SHARDS, s->stream));
   double ms = 0, trace_ms = 0;
   uint64_t launches = 0;
-  int rc = run_passes(s, (uint32_t)s->spp_done, &ms, &trace_ms, &launches);
-  if (rc) return rc;
+  // one block of JADE_SAMPLE_LANES samples at a time (see PathState): records may not run
+  // ahead into the next block while another record still owns a (pixel, lane) sum of this one
+  for (int64_t from = s->spp_done - spp; from < s->spp_done;) {
+    int64_t to = (from / JADE_SAMPLE_LANES + 1) * JADE_SAMPLE_LANES;
+    if (to > s->spp_done || s->ps.stride == 0) to = s->spp_done;  // no rotation: no block barrier needed
+    double m1 = 0, t1 = 0;
+    uint64_t l1 = 0;
+    int rc = run_passes(s, (uint32_t)to, &m1, &t1, &l1);
+    if (rc) return rc;
+    ms += m1; trace_ms += t1; launches += l1;
+    from = to;
+  }
   if (st) {
     DevCounters c{};
     HIP_TRY(sum_counters(s, &c));
@@ -863,7 +895,7 @@ static int resolve_to(jade_scene* s, int tonemap, float limit, float* dev_rgb, u
   const int npix = s->ps.npx;
   if (npix == 0) return JADE_OK;
   float inv = (float)(1.0 / (double)s->spp_done);  // vec3(1.0 / spp), PathTrace.cu:1457
-  hipLaunchKernelGGL(k_resolve, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream, s->ps, inv, tonemap, limit, dev_rgb, dev_bgr);
+  hipLaunchKernelGGL(k_resolve, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream, s->ps, s->rc, s->b_tiles.as<int32_t>(), inv, tonemap, limit, dev_rgb, dev_bgr);
   HIP_TRY(hipGetLastError());
   return JADE_OK;
 }
