@@ -70,12 +70,14 @@ static __device__ __forceinline__ NextSample next_sample(const PathState& P, int
   r.pixel = (int)(((unsigned long long)home + (unsigned long long)n * (uint32_t)P.stride) % (uint32_t)P.npx);
   return r;
 }
-static __device__ __forceinline__ bool pixel_xy(const RenderConst& R, const int32_t* tile_ids, int pixel, int* x, int* y) {
-  int t = pixel >> 8, l = pixel & 255;
-  int tid = tile_ids[t];
+static __device__ __forceinline__ bool pixel_xy_t(const RenderConst& R, int tid, int pixel, int* x, int* y) {
+  int l = pixel & 255;
   *x = (tid % R.tiles_x) * JADE_TILE_SIZE + (l & 15);
   *y = (tid / R.tiles_x) * JADE_TILE_SIZE + (l >> 4);
   return *x < R.width && *y < R.height;
+}
+static __device__ __forceinline__ bool pixel_xy(const RenderConst& R, const int32_t* tile_ids, int pixel, int* x, int* y) {
+  return pixel_xy_t(R, tile_ids[pixel >> 8], pixel, x, y);
 }
 
 __global__ void k_selftest(QueueCtl* q, float one) { q->fp_bad = (uint32_t)jade_fp_selftest(one); }
@@ -128,15 +130,26 @@ __global__ __launch_bounds__(256, JADE_SHADE_WAVES) void k_shade(DevScene S, Pat
   c.n_emit_rays = 0;
   c.c_primary = c.c_secondary = c.c_shaded = c.c_samples = 0;
   uint32_t st = ST_INVALID;
-  if (p < npix) st = P.stage[p] & 255u;
+  // Prologue: everything most record-passes need, requested together so the pass is one
+  // round trip deep instead of one per field (the kernel is latency-bound: PMC shows its
+  // waves parked on s_waitcnt 74 % of the time).
+  const int pp = p < npix ? p : 0;
+  const uint32_t word = P.stage[pp];
+  const uint32_t rng0 = P.rng[pp];
+  const uint32_t done0 = P.done[pp];
+  const int hit0 = P.hit[pp];
+  const size_t pl0 = (size_t)P.nslots * npix;
+  const jvec3 dir0 = jv(P.dir[pp], P.dir[pl0 + pp], P.dir[2 * pl0 + pp]);
+  const int home_pix = pp % P.npx;
+  const int tid0 = tile_ids[home_pix >> 8];
+  if (p < npix) st = word & 255u;
   if (st != ST_INVALID) {
-    const uint32_t word = P.stage[p];
     const Px px(P, p);
     // State is loaded and stored by need: a background record (camera ray ->
     // sky, or -> mirror floor -> sky) touches ~90 B per pass, not the whole
     // ~230-B record; only records on a multi-bounce path carry thr/acc/le/....
     const bool on_path = st >= ST_DIFFUSE && st <= ST_REFRACT_EXIT;
-    c.rng = P.rng[p];
+    c.rng = rng0;
     c.depth = (word >> 8) & 255u;
     c.flags = word >> 16;
     c.stage = st;
@@ -154,15 +167,15 @@ __global__ __launch_bounds__(256, JADE_SHADE_WAVES) void k_shade(DevScene S, Pat
       c.src = ld3(P.src, npix, p);
       c.out = ld3(P.out, npix, p);
     }
-    uint32_t done = P.done[p];
+    uint32_t done = done0;
     jvec3 l_final;
     bool finished = false;  // a sample ended: colour in `color`
     jvec3 color = jv(0, 0, 0);
 
     // (a) fold in the results of the rays issued by the previous pass
     if (st == ST_PRIMARY) {
-      int h = px.hit(0);
-      jvec3 d = px.dir(0);
+      int h = hit0;
+      jvec3 d = dir0;
       if (h < 0) {
         color = sample_hdr(S, d);  // PathTrace.cu:1443-1445
         finished = true;
@@ -217,7 +230,7 @@ __global__ __launch_bounds__(256, JADE_SHADE_WAVES) void k_shade(DevScene S, Pat
         // next sample of this record; samples of out-of-image pixels (edge tiles) are skipped
         int x, y;
         NextSample ns = next_sample(P, p, done);
-        while (ns.sidx < target_spp && !pixel_xy(R, tile_ids, ns.pixel, &x, &y)) {
+        while (ns.sidx < target_spp && !pixel_xy_t(R, ns.pixel == home_pix ? tid0 : tile_ids[ns.pixel >> 8], ns.pixel, &x, &y)) {
           done += 1;
           ns = next_sample(P, p, done);
         }
