@@ -71,6 +71,11 @@ int jadeh_builder_load_render_args(jadeh_builder* b, const char* path, jadeh_con
 
 /* prefix sums + SAH BVH (leaf_size 8 in the reference) + encode */
 jadeh_scene* jadeh_builder_build(jadeh_builder* b, int leaf_size);
+/* the same flattening around a BVH built elsewhere (include/jade_bvh.h: the GPU LBVH builder):
+ * jadeh_builder_triangles() gives that builder its input (original order), and
+ * jadeh_builder_build_with_bvh() takes its output (order[i] = original index of sorted triangle i) */
+int jadeh_builder_triangles(const jadeh_builder* b, jade_triangle* out, int capacity);
+jadeh_scene* jadeh_builder_build_with_bvh(jadeh_builder* b, const int32_t* order, const jade_bvh_node* nodes, int n_nodes);
 void jadeh_scene_free(jadeh_scene* s);
 void jadeh_scene_desc(const jadeh_scene* s, jade_scene_desc* out); /* pointers owned by s */
 int jadeh_scene_bvh_depth(const jadeh_scene* s);

@@ -109,6 +109,12 @@ RT_SYMBOLS = {
                                   C.c_void_p, C.POINTER(Stats)]),
 }
 
+# include/jade_bvh.h (exported by libjade_hip.so)
+BVH_SYMBOLS = {
+    "jade_bvh_build_lbvh": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int, C.c_void_p, C.c_void_p, C.c_int32,
+                                      C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
+}
+
 HOST_SYMBOLS = {
     "jadeh_last_error": (C.c_char_p, []),
     "jadeh_builder_new": (C.c_void_p, []),
@@ -127,6 +133,8 @@ HOST_SYMBOLS = {
     "jadeh_builder_config": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(Config)]),
     "jadeh_builder_load_render_args": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(Config)]),
     "jadeh_builder_build": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "jadeh_builder_triangles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "jadeh_builder_build_with_bvh": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "jadeh_scene_free": (None, [C.c_void_p]),
     "jadeh_scene_desc": (None, [C.c_void_p, C.POINTER(SceneDesc)]),
     "jadeh_scene_bvh_depth": (C.c_int, [C.c_void_p]),

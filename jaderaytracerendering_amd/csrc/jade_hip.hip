@@ -458,10 +458,11 @@ __global__ void k_resolve(PathState P, RenderConst R, const int32_t* tile_ids, f
 // ---------------------------------------------------------------- host side --
 
 static thread_local std::string g_err;
-static int fail(int code, const std::string& msg) {
+int jade_fail(int code, const std::string& msg) {  // shared with jade_bvh.hip
   g_err = msg;
   return code;
 }
+static int fail(int code, const std::string& msg) { return jade_fail(code, msg); }
 #define HIP_TRY(expr)                                                                      \
   do {                                                                                     \
     hipError_t e_ = (expr);                                                                \

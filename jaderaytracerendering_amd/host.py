@@ -220,6 +220,38 @@ class SceneBuilder:
     def triangle_count(self):
         return self._lib.jadeh_builder_triangle_count(self._h)
 
+    def triangles_original(self):
+        """(n, 28) uint32 view of the Triangle_cu records in ORIGINAL order (input of an external BVH builder)."""
+        n = self.triangle_count
+        out = np.zeros((n, 28), np.uint32)
+        _check(self._lib.jadeh_builder_triangles(self._h, out.ctypes.data, n))
+        return out
+
+    def build_with_bvh(self, order, nodes):
+        """Flatten around a BVH built elsewhere: order[i] = original index of sorted triangle i."""
+        order = np.ascontiguousarray(order, np.int32)
+        nodes = np.ascontiguousarray(nodes, np.uint32).reshape(-1, 10)
+        h = self._lib.jadeh_builder_build_with_bvh(self._h, order.ctypes.data, nodes.ctypes.data, len(nodes))
+        if not h:
+            raise RuntimeError(self._lib.jadeh_last_error().decode())
+        try:
+            return HostScene.from_handle(h)
+        finally:
+            self._lib.jadeh_scene_free(h)
+
+    def build_lbvh(self, backend, leaf_size=8, device_id=0):
+        """BVH built on the GPU (include/jade_bvh.h); returns (HostScene, device build milliseconds)."""
+        tris = self.triangles_original()
+        n = len(tris)
+        lib = _abi.bind(backend.lib, _abi.BVH_SYMBOLS)
+        order = np.zeros(n, np.int32)
+        nodes = np.zeros((2 * n + 1, 10), np.uint32)
+        n_nodes = C.c_int32(0)
+        ms = C.c_double(0)
+        backend.check(lib.jade_bvh_build_lbvh(tris.ctypes.data, n, leaf_size, device_id, order.ctypes.data, nodes.ctypes.data,
+                                              len(nodes), C.byref(n_nodes), C.byref(ms)))
+        return self.build_with_bvh(order, nodes[: n_nodes.value]), ms.value
+
     def build(self, leaf_size=8):
         h = self._lib.jadeh_builder_build(self._h, leaf_size)
         if not h:

@@ -166,6 +166,29 @@ jadeh_scene* jadeh_builder_build(jadeh_builder* b, int leaf_size) {
   s->s = b->b.build(leaf_size > 0 ? leaf_size : 8);
   return s;
 }
+int jadeh_builder_triangles(const jadeh_builder* b, jade_triangle* out, int capacity) {
+  if (!b || !out) return fail("builder_triangles: bad arguments");
+  std::vector<jade_triangle> v = b->b.triangles_original();
+  if ((int)v.size() > capacity) return fail("builder_triangles: buffer too small");
+  memcpy(out, v.data(), v.size() * sizeof(jade_triangle));
+  return 0;
+}
+
+jadeh_scene* jadeh_builder_build_with_bvh(jadeh_builder* b, const int32_t* order, const jade_bvh_node* nodes, int n_nodes) {
+  if (!b || b->b.triangle_count() == 0) {
+    fail("build_with_bvh: empty scene");
+    return nullptr;
+  }
+  jadeh_scene* s = new jadeh_scene();
+  std::string err;
+  if (!b->b.build_with_bvh(order, nodes, n_nodes, s->s, err)) {
+    fail(err);
+    delete s;
+    return nullptr;
+  }
+  return s;
+}
+
 void jadeh_scene_free(jadeh_scene* s) { delete s; }
 void jadeh_scene_desc(const jadeh_scene* s, jade_scene_desc* out) {
   if (s && out) *out = s->s.desc();

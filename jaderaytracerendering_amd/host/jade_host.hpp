@@ -94,8 +94,14 @@ class SceneBuilder {
   // Area prefix sums (PathTrace.cu:1539-1546), SAH BVH with leaf size 8
   // (:1557-1565), encode (:1570-1612).
   BuiltScene build(int leaf_size = 8) const;
+  // The same flattening around a BVH built elsewhere (e.g. jade_bvh_build_lbvh on the GPU):
+  // `order[i]` = original index of the triangle at sorted position i, `nodes` in the reference's
+  // conventions.  triangles_original() is what such a builder takes as input.
+  std::vector<jade_triangle> triangles_original() const;
+  bool build_with_bvh(const int32_t* order, const jade_bvh_node* nodes, int n_nodes, BuiltScene& out, std::string& err) const;
 
  private:
+  void finish(std::vector<HostTriangle>& sorted, BuiltScene& out) const;
   std::vector<HostTriangle> tris_;
   std::vector<jade_obj_seg> segs_;
   EnvMap env_;

@@ -438,54 +438,92 @@ jade_scene_desc BuiltScene::desc() const {
   return d;
 }
 
-BuiltScene SceneBuilder::build(int leaf_size) const {
-  auto t0 = std::chrono::steady_clock::now();
-  BuiltScene out;
-  std::vector<HostTriangle> tris = tris_;
+static void encode_triangle(const HostTriangle& t, jade_triangle& e) {
+  const Material& m = t.material;
+  e.obj_idx = t.obj_idx;
+  e.p1[0] = t.p1.x; e.p1[1] = t.p1.y; e.p1[2] = t.p1.z;
+  e.p2[0] = t.p2.x; e.p2[1] = t.p2.y; e.p2[2] = t.p2.z;
+  e.p3[0] = t.p3.x; e.p3[1] = t.p3.y; e.p3[2] = t.p3.z;
+  e.norm[0] = t.norm.x; e.norm[1] = t.norm.y; e.norm[2] = t.norm.z;
+  std::memcpy(e.emissive, m.emissive, sizeof e.emissive);
+  std::memcpy(e.brdf, m.brdf, sizeof e.brdf);
+  e.reflex_mode = m.reflex_mode;
+  e.refract_mode = m.refract_mode;
+  std::memcpy(e.refract_rate, m.refract_rate, sizeof e.refract_rate);
+  std::memcpy(e.refract_albedo, m.refract_albedo, sizeof e.refract_albedo);
+  e.refract_index = m.refract_index;
+}
+
+// Everything of PathTrace.cu:1539-1612 except the BVH itself: prefix sums in original order,
+// encode in sorted order, original -> sorted mapping, emitter list.
+void SceneBuilder::finish(std::vector<HostTriangle>& tris, BuiltScene& out) const {
   size_t n = tris.size();
   out.segs = segs_;
-  // area prefix sums in ORIGINAL order, restarting per object (PathTrace.cu:1539-1546)
   out.prefix.resize(n);
   for (const jade_obj_seg& seg : segs_) {
     float size_sum = 0;
     for (int idx = seg.begin_idx; idx <= seg.end_idx; ++idx) {
-      size_sum += host_tri_area(tris[idx]);
+      size_sum += host_tri_area(tris_[idx]);
       out.prefix[idx] = size_sum;
     }
   }
-  // dummy node 0 (PathTrace.cu:1557-1563), root becomes node 1
+  out.bvh_depth = bvh_depth(out.nodes);
+  out.triangles.resize(n);
+  out.mapping.resize(n);
+  out.emit.clear();
+  for (size_t i = 0; i < n; ++i) {
+    const HostTriangle& t = tris[i];
+    encode_triangle(t, out.triangles[i]);
+    out.mapping[t.index] = (int32_t)i;
+    const Material& m = t.material;
+    if (m.emissive[0] > 1.5e-4f || m.emissive[1] > 1.5e-4f || m.emissive[2] > 1.5e-4f) out.emit.push_back((int32_t)i);
+  }
+  out.env = env_.width > 0 ? env_ : make_env_constant(0, 0, 0);
+}
+
+static jade_bvh_node dummy_node() {  // PathTrace.cu:1557-1563
   jade_bvh_node dummy;
   std::memset(&dummy, 0, sizeof dummy);
   dummy.left = 255; dummy.right = 128; dummy.n = 30;
   dummy.aa[0] = 1; dummy.aa[1] = 1; dummy.bb[1] = 1;
-  out.nodes.push_back(dummy);
-  if (n > 0) build_bvh_sah(tris, out.nodes, leaf_size);
-  out.bvh_depth = bvh_depth(out.nodes);
+  return dummy;
+}
 
-  out.triangles.resize(n);
-  out.mapping.resize(n);
-  for (size_t i = 0; i < n; ++i) {
-    const HostTriangle& t = tris[i];
-    const Material& m = t.material;
-    jade_triangle& e = out.triangles[i];
-    e.obj_idx = t.obj_idx;
-    out.mapping[t.index] = (int32_t)i;
-    e.p1[0] = t.p1.x; e.p1[1] = t.p1.y; e.p1[2] = t.p1.z;
-    e.p2[0] = t.p2.x; e.p2[1] = t.p2.y; e.p2[2] = t.p2.z;
-    e.p3[0] = t.p3.x; e.p3[1] = t.p3.y; e.p3[2] = t.p3.z;
-    e.norm[0] = t.norm.x; e.norm[1] = t.norm.y; e.norm[2] = t.norm.z;
-    std::memcpy(e.emissive, m.emissive, sizeof e.emissive);
-    std::memcpy(e.brdf, m.brdf, sizeof e.brdf);
-    e.reflex_mode = m.reflex_mode;
-    e.refract_mode = m.refract_mode;
-    std::memcpy(e.refract_rate, m.refract_rate, sizeof e.refract_rate);
-    std::memcpy(e.refract_albedo, m.refract_albedo, sizeof e.refract_albedo);
-    e.refract_index = m.refract_index;
-    if (m.emissive[0] > 1.5e-4f || m.emissive[1] > 1.5e-4f || m.emissive[2] > 1.5e-4f) out.emit.push_back((int32_t)i);
-  }
-  out.env = env_.width > 0 ? env_ : make_env_constant(0, 0, 0);
+BuiltScene SceneBuilder::build(int leaf_size) const {
+  auto t0 = std::chrono::steady_clock::now();
+  BuiltScene out;
+  std::vector<HostTriangle> tris = tris_;
+  out.nodes.push_back(dummy_node());  // root becomes node 1
+  if (!tris.empty()) build_bvh_sah(tris, out.nodes, leaf_size);
+  finish(tris, out);
   out.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return out;
+}
+
+std::vector<jade_triangle> SceneBuilder::triangles_original() const {
+  std::vector<jade_triangle> v(tris_.size());
+  for (size_t i = 0; i < tris_.size(); ++i) encode_triangle(tris_[i], v[i]);
+  return v;
+}
+
+bool SceneBuilder::build_with_bvh(const int32_t* order, const jade_bvh_node* nodes, int n_nodes, BuiltScene& out,
+                                  std::string& err) const {
+  auto t0 = std::chrono::steady_clock::now();
+  const size_t n = tris_.size();
+  if (!order || !nodes || n_nodes < 2) { err = "build_with_bvh: missing BVH"; return false; }
+  std::vector<char> seen(n, 0);
+  std::vector<HostTriangle> tris(n);
+  for (size_t i = 0; i < n; ++i) {
+    if (order[i] < 0 || (size_t)order[i] >= n || seen[order[i]]) { err = "build_with_bvh: order is not a permutation"; return false; }
+    seen[order[i]] = 1;
+    tris[i] = tris_[order[i]];
+  }
+  out = BuiltScene();
+  out.nodes.assign(nodes, nodes + n_nodes);
+  out.nodes[0] = dummy_node();
+  finish(tris, out);
+  out.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return true;
 }
 
 }  // namespace jadehost

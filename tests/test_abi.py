@@ -20,6 +20,7 @@ def _declared_symbols(header):
 def test_python_tables_cover_the_headers():
     assert _declared_symbols("jade_rt.h") == set(_abi.RT_SYMBOLS)
     assert _declared_symbols("jade_host_c.h") == set(_abi.HOST_SYMBOLS)
+    assert _declared_symbols("jade_bvh.h") == set(_abi.BVH_SYMBOLS)
 
 
 @pytest.mark.parametrize("which", ["hip", "oracle"])
@@ -30,6 +31,8 @@ def test_library_loads_and_exports_every_symbol(which):
     for name in _abi.RT_SYMBOLS:
         assert hasattr(lib, name), f"{path} lacks {name}"
     _abi.bind(lib, _abi.RT_SYMBOLS)
+    if which == "hip":
+        _abi.bind(lib, _abi.BVH_SYMBOLS)   # include/jade_bvh.h lives in the HIP library only
     assert lib.jade_abi_version() == _abi.JADE_ABI_VERSION
     assert lib.jade_backend_name().decode() == ("hip-gfx950" if which == "hip" else "oracle-cpu")
     assert lib.jade_owned_tile_count(1920, 1080, 0, 8) == 1020  # 120 x 68 tiles, diagonal deal

@@ -1,0 +1,117 @@
+"""include/jade_bvh.h: the device-side LBVH builder.
+
+Bar: the tree obeys the reference's conventions and invariants, traversing it finds exactly what a
+brute-force scan finds, the HIP integrator on it matches the oracle on it (counters exact), and the
+image agrees with the SAH scene's image up to the reference's tree-dependent corner cases."""
+import numpy as np
+import pytest
+
+from conftest import B, J, counters, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _builder(name):
+    b = J.SceneBuilder()
+    cfg = b.config(name)
+    return b, cfg
+
+
+def _check_invariants(hs, leaf_max=8):
+    ni, nf, v = hs.node_i32(), hs.node_f32(), hs.vertices()
+    nT = hs.n_triangles
+    assert tuple(ni[0, :3]) == (255, 128, 30)
+    seen = np.zeros(nT, np.int32)
+    stack, depth = [(1, 1)], 0
+    while stack:
+        i, d = stack.pop()
+        depth = max(depth, d)
+        l, r, n, first = ni[i, :4]
+        aa, bb = nf[i, 4:7], nf[i, 7:10]
+        if n > 0:
+            assert 1 <= n <= leaf_max and l == 0 and r == 0
+            seen[first:first + n] += 1
+            tv = v[first:first + n].reshape(-1, 3)
+            assert np.array_equal(tv.min(0), aa) and np.array_equal(tv.max(0), bb)
+        else:
+            assert l > 0 and r > 0
+            # parent box = union of the children's boxes, exactly
+            assert np.array_equal(np.minimum(nf[l, 4:7], nf[r, 4:7]), aa) and np.array_equal(np.maximum(nf[l, 7:10], nf[r, 7:10]), bb)
+            stack += [(l, d + 1), (r, d + 1)]
+    assert (seen == 1).all() and depth == hs.bvh_depth < 127
+    assert np.array_equal(np.sort(hs.a["mapping"]), np.arange(nT))
+    return depth
+
+
+@pytest.mark.parametrize("name", ["tiny", "tinyjade", "C2"])
+def test_lbvh_invariants_and_brute_force(oracle, hip, name):
+    b, cfg = _builder(name)
+    lb, ms = b.build_lbvh(hip)
+    flat = b.build(10 ** 9)
+    _check_invariants(lb)
+    assert ms > 0
+    rng = np.random.default_rng(5)
+    n = 4000
+    vv = lb.vertices().reshape(-1, 3)
+    ctr, ext = (vv.min(0) + vv.max(0)) / 2, np.ptp(vv, axis=0).max()
+    o = (ctr + (rng.random((n, 3)) - 0.5) * ext * 1.2).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    skip = np.full(n, -1, np.int32)
+    with oracle.scene(lb) as st, oracle.scene(flat) as sf, hip.scene(lb) as sh:
+        it, dt, pt, _ = st.trace_rays(o, d, skip)
+        i_f, df, pf, _ = sf.trace_rays(o, d, skip)
+        ih, dh, ph, _ = sh.trace_rays(o, d, skip)
+    h = it >= 0
+    assert np.array_equal(h, i_f >= 0) and h.sum() > 100
+    assert np.array_equal(dt[h].view(np.uint32), df[h].view(np.uint32))          # same distance as a full scan
+    assert np.array_equal(lb.vertices()[it[h]], flat.vertices()[i_f[h]])          # ... on the same triangle
+    assert np.array_equal(it, ih) and np.array_equal(pt[h].view(np.uint32), ph[h].view(np.uint32))
+
+
+def test_lbvh_render_parity_and_agreement_with_sah(oracle, hip):
+    b, cfg = _builder("tinyjade")
+    lb, _ = b.build_lbvh(hip)
+    sah = b.build()
+    p = B.params_from_config(cfg, spp=8)
+    with oracle.scene(lb) as so, hip.scene(lb) as sh, hip.scene(sah) as ss:
+        r_o, b_o, st_o = so.render(p)
+        r_h, b_h, st_h = sh.render(p)
+        r_s, b_s, st_s = ss.render(p)
+    assert counters(st_h) == counters(st_o) and rel_l2(r_h, r_o) <= 1e-4         # HIP == oracle on the LBVH tree
+    # Across trees: random rays agree exactly (test above), but the reference's intersection code has
+    # no epsilon, so a ray leaving a large coplanar face (mirror floor) "hits" the coplanar neighbour
+    # at ~1e-7 whenever that neighbour's leaf is entered.  The SAH tree gives those triangles a FLAT
+    # leaf box, which the "slab value > 0" rule (PathTrace.cu:770, 835-855) skips; another tree may
+    # not.  So camera rays and sample counts are identical, most pixels are identical, the rest differ.
+    assert st_h.rays_primary == st_s.rays_primary and st_h.samples == st_s.samples
+    same = (np.abs(r_h - r_s) <= 1e-5 * np.maximum(np.abs(r_s), 1e-3)).all(axis=2)
+    assert same.mean() > 0.8
+
+
+def test_lbvh_on_the_870k_scene(oracle, hip):
+    """configs[4] geometry: build on the GPU in milliseconds (host SAH: ~8 s), then parity on a subset."""
+    b, cfg = _builder("C5")
+    lb, ms = b.build_lbvh(hip)
+    depth = _check_invariants(lb)
+    print(f"LBVH 873,634 triangles: {ms:.2f} ms on device, {lb.n_nodes} nodes, depth {depth}")
+    assert ms < 200
+    p = B.params_from_config(cfg, spp=2)
+    p.width, p.height = 64, 36
+    with oracle.scene(lb) as so, hip.scene(lb) as sh:
+        r_o, _, st_o = so.render(p)
+        r_h, _, st_h = sh.render(p)
+    assert counters(st_h) == counters(st_o) and rel_l2(r_h, r_o) <= 1e-4
+
+
+def test_lbvh_edge_cases(hip):
+    from jaderaytracerendering_amd import host as H
+    for ntri in (1, 2, 9):
+        bb = J.SceneBuilder()
+        v = np.random.default_rng(ntri).random((3 * ntri, 3)).astype(np.float32)
+        bb.add_mesh(v, np.arange(3 * ntri).reshape(-1, 3), H.material())
+        hs, _ = bb.build_lbvh(hip)
+        _check_invariants(hs)
+        with hip.scene(hs) as sc:
+            idx, _, _, _ = sc.trace_rays(v[:3].mean(0)[None] + [[0, 0, 5]], [[0, 0, -1]], [-1])
+    with pytest.raises(B.JadeError):
+        bb.build_lbvh(hip, leaf_size=99)
