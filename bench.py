@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bvh", default="sah", choices=["sah", "lbvh"],
+                    help="sah: the reference's host builder (default, what the metric is quoted on); lbvh: GPU builder")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL) for real runs; gloo rehearses the multi-rank flow with every rank on one GPU")
     ap.add_argument("--virtual-ranks", type=int, default=0,
@@ -82,7 +84,14 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     t0 = time.time()
-    hs, cfg = J.build_config(args.config)
+    lbvh_ms = None
+    if args.bvh == "lbvh":
+        sb = J.SceneBuilder()
+        cfg = sb.config(args.config)
+        hs, lbvh_ms = sb.build_lbvh(hip, device_id=local_rank if args.dist_backend != "gloo" else 0)
+        sb.close()
+    else:
+        hs, cfg = J.build_config(args.config)
     build_s = time.time() - t0
     width = args.width or cfg.width
     height = args.height or cfg.height
@@ -174,6 +183,8 @@ def main():
             "gather_ms": gather_ms,
             "frame_ok": frame_ok,
             "scene_build_s": build_s,
+            "bvh": args.bvh, "lbvh_device_ms": lbvh_ms,
+            "nodes_per_ray": float(vals[1].item()) / rays_all, "tris_per_ray": float(vals[2].item()) / rays_all,
             "roofline": {
                 "bound": "hbm", "kernel": "k_trace", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
