@@ -43,8 +43,21 @@ hipvariants: $(LIBDIR)/libjade_hip_stack4.so
 $(LIBDIR)/jade_render: $(PKG)/host/jade_render_cli.cpp $(LIBDIR)/libjade_host.so $(HOST_HDR)
 	$(CXX) $(CXXFLAGS) -o $@ $(PKG)/host/jade_render_cli.cpp -L$(LIBDIR) -ljade_host -ldl -Wl,-rpath,'$$ORIGIN'
 
+# AddressSanitizer + UBSan over the CPU side (host pipeline, CLI, oracle).  GPU ASan is not
+# available on the pool, so this is where memory errors of the non-device code are hunted.
+SAN := -fsanitize=address,undefined -fno-omit-frame-pointer -O1 -g
+asan-check:
+	@mkdir -p $(ROOT)/tests/_build/asan
+	$(CXX) $(CXXFLAGS) $(SAN) -shared -o $(ROOT)/tests/_build/asan/libjade_host.so $(HOST_SRC)
+	gcc -std=gnu11 -fPIC -ffp-contract=off -mfma $(SAN) -I$(ROOT)/include -shared -o $(ROOT)/tests/_build/asan/libjade_oracle.so $(ROOT)/oracle/jade_oracle.c -lpthread -lm
+	$(CXX) $(CXXFLAGS) $(SAN) -o $(ROOT)/tests/_build/asan/jade_render $(PKG)/host/jade_render_cli.cpp -L$(ROOT)/tests/_build/asan -ljade_host -ldl -Wl,-rpath,'$$ORIGIN'
+	cd $(ROOT)/tests/_build/asan && for c in tiny tinyjade C1; do \
+	  ASAN_OPTIONS=detect_leaks=1 ./jade_render --config $$c --width 48 --height 40 --spp 3 --backend ./libjade_oracle.so --out o_$$c.bmp || exit 1; done
+	cd $(ROOT)/tests/_build/asan && ./jade_render --config C2 --width 24 --height 24 --spp 2 --backend ./libjade_oracle.so --out o_C2.ppm
+	@echo "asan-check: clean"
+
 clean:
 	rm -rf $(LIBDIR)
 	$(MAKE) -C $(ROOT)/oracle clean
 
-.PHONY: all host hip hipvariants oracle cli clean
+.PHONY: all host hip hipvariants oracle cli clean asan-check

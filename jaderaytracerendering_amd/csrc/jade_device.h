@@ -132,7 +132,9 @@ struct DevCounters {
   unsigned long long rays_primary, rays_secondary, nodes_visited, tris_tested, shaded_hits, samples;
   unsigned long long pad[2];
 };
+#ifndef JADE_TRACE_CHUNK
 #define JADE_TRACE_CHUNK 512 /* most rays a wave claims per queue atomic */
+#endif
 #define JADE_REFILL_MIN 16    /* idle lanes in a wave that trigger a refill */
 #ifndef JADE_PHASED
 #define JADE_PHASED 0       /* 1: run one kind of traversal unit per wave iteration (measured slower: 2067 vs 2214 Mray/s) */
