@@ -204,6 +204,17 @@ int jade_render_resolve_ex(jade_scene* scene, int tonemap, float limit, float* o
 int jade_render_resolve_tiles_device(jade_scene* scene, float* dev_tiles, void* stream);
 int jade_owned_tile_count(int32_t width, int32_t height, int32_t tile_rank, int32_t tile_nranks);
 
+/* One frame on several GPUs from ONE process.  scenes[i] must have been created
+ * on the device that renders share i (jade_scene_create(desc, device_i, ..)); tiles are dealt
+ * (tx + ty) % ndev exactly as with tile_rank / tile_nranks, every device renders its share
+ * concurrently (one host thread per device), then device scenes[0] lives on collects the compact
+ * tile buffers with peer-to-peer copies (xGMI) and the frame is assembled and tone-mapped once.
+ * The result is bit-identical to jade_render on one device.  params->tile_rank / tile_nranks /
+ * device_id are ignored.  (The one-process-per-GPU form with an RCCL gather is what bench.py and
+ * jaderaytracerendering_amd/distributed.py use.) */
+int jade_render_multi(jade_scene* const* scenes, int ndev, const jade_render_params* params,
+                      float* out_rgb, uint8_t* out_bgr8, jade_stats* stats);
+
 /* Single-query entry point used by the parity tests: traces `n` rays through
  * the scene's BVH with hitBVH semantics (PathTrace.cu:795-859).
  *   origins/dirs: n*3 floats; skip: n source-triangle indices (-1 = none)

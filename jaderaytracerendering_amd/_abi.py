@@ -99,6 +99,8 @@ RT_SYMBOLS = {
     "jade_scene_create": (C.c_int, [C.POINTER(SceneDesc), C.c_int, C.POINTER(C.c_void_p)]),
     "jade_scene_destroy": (None, [C.c_void_p]),
     "jade_render": (C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.POINTER(Stats)]),
+    "jade_render_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(RenderParams), C.c_void_p, C.c_void_p,
+                                    C.POINTER(Stats)]),
     "jade_render_begin": (C.c_int, [C.c_void_p, C.POINTER(RenderParams)]),
     "jade_render_step": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(Stats)]),
     "jade_render_resolve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -140,6 +140,18 @@ class Scene:
         return idx, dist, pt, st
 
 
+def render_multi(backend, scenes, params, want_rgb=True, want_bgr8=True):
+    """jade_render_multi: one frame over several scenes (one per device) from this process."""
+    h, w = params.height, params.width
+    rgb = np.zeros((h, w, 3), np.float32) if want_rgb else None
+    bgr = np.zeros((h, w, 3), np.uint8) if want_bgr8 else None
+    st = _abi.Stats()
+    arr = (C.c_void_p * len(scenes))(*[s._h for s in scenes])
+    backend.check(backend.lib.jade_render_multi(arr, len(scenes), C.byref(params), rgb.ctypes.data if want_rgb else None,
+                                                bgr.ctypes.data if want_bgr8 else None, C.byref(st)))
+    return rgb, bgr, st
+
+
 _hip = None
 
 

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <thread>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -977,6 +978,119 @@ int jade_render(jade_scene* s, const jade_render_params* rp, float* out_rgb, uin
   rc = jade_render_step(s, rp->spp, st);
   if (rc) return rc;
   return jade_render_resolve(s, out_rgb, out_bgr8);
+}
+
+// host twin of k_resolve's tone map + pack (same jade_fpmath.h routines, same flags: same bits)
+static void tonemap_pack_host(const float* m, int tonemap, float limit, uint8_t* bgr) {
+  float v[3] = {m[0], m[1], m[2]};
+  float rein = 1.0f;
+  if (tonemap == JADE_TONEMAP_REINHARD) {
+    float luminance = (float)(0.3 * (double)m[0] + 0.6 * (double)m[1] + 0.1 * (double)m[2]);
+    rein = (float)(1.0 / (1.0 + (double)(luminance / limit)));
+  }
+  for (int k = 0; k < 3; ++k) {
+    float x = v[k];
+    if (tonemap == JADE_TONEMAP_REINHARD) {
+      x = x * rein;
+    } else {
+      float num = x * (x * 2.51f + 0.03f);
+      float den = x * (x * 2.43f + 0.59f) + 0.14f;
+      x = num / den;
+    }
+    x = jade_powf(x, (float)(1.0 / 2.2));
+    x = x * 255.0f;
+    x = x > 255 ? 255 : x;
+    v[k] = x;
+  }
+  for (int k = 0; k < 3; ++k) {
+    float x = v[2 - k];
+    bgr[k] = (x >= 0.0f) ? (uint8_t)x : (uint8_t)0;
+  }
+}
+
+int jade_render_multi(jade_scene* const* scenes, int ndev, const jade_render_params* rp, float* out_rgb, uint8_t* out_bgr8,
+                      jade_stats* st) {
+  if (!scenes || ndev <= 0 || !rp) return fail(JADE_ERR_INVALID, "null argument");
+  if (rp->spp <= 0 || rp->width <= 0 || rp->height <= 0) return fail(JADE_ERR_INVALID, "bad image size or spp");
+  for (int i = 0; i < ndev; ++i)
+    if (!scenes[i]) return fail(JADE_ERR_INVALID, "null scene");
+  // 1. every device renders its share (one host thread each) and resolves it into a device buffer
+  std::vector<int> rcs(ndev, JADE_OK);
+  std::vector<std::string> msgs(ndev);
+  std::vector<jade_stats> sts(ndev);
+  for (auto& x : sts) memset(&x, 0, sizeof x);
+  auto work = [&](int i) {
+    jade_scene* s = scenes[i];
+    jade_render_params p = *rp;
+    p.tile_rank = i;
+    p.tile_nranks = ndev;
+    p.device_id = s->device;
+    int rc = jade_render_begin(s, &p);
+    if (rc == JADE_OK) rc = jade_render_step(s, p.spp, &sts[i]);
+    if (rc == JADE_OK && s->ps.npx > 0) {
+      hipError_t e = s->b_out_rgb.alloc((size_t)s->ps.npx * 12);
+      if (e != hipSuccess) rc = jade_fail(JADE_ERR_NOMEM, "tile buffer allocation failed");
+      if (rc == JADE_OK) rc = resolve_to(s, JADE_TONEMAP_ACES, 0.0f, s->b_out_rgb.as<float>(), nullptr, s->stream);
+      if (rc == JADE_OK && hipStreamSynchronize(s->stream) != hipSuccess) rc = jade_fail(JADE_ERR_DEVICE, "stream sync failed");
+    }
+    rcs[i] = rc;
+    if (rc) msgs[i] = g_err;  // g_err is thread-local: carry the text back to the caller's thread
+  };
+  std::vector<std::thread> th;
+  for (int i = 1; i < ndev; ++i) th.emplace_back(work, i);
+  work(0);
+  for (auto& t : th) t.join();
+  for (int i = 0; i < ndev; ++i)
+    if (rcs[i]) return fail(rcs[i], "device share " + std::to_string(i) + ": " + msgs[i]);
+  // 2. gather on the device of scenes[0]: peer-to-peer copies of the compact tile buffers
+  jade_scene* s0 = scenes[0];
+  HIP_TRY(hipSetDevice(s0->device));
+  size_t total = 0;
+  std::vector<size_t> off(ndev);
+  for (int i = 0; i < ndev; ++i) {
+    off[i] = total;
+    total += (size_t)scenes[i]->ps.npx * 3;
+  }
+  DevBuf gather;
+  HIP_TRY(gather.alloc(total * 4));
+  for (int i = 0; i < ndev; ++i) {
+    size_t bytes = (size_t)scenes[i]->ps.npx * 12;
+    if (!bytes) continue;
+    HIP_TRY(hipMemcpyPeerAsync(gather.as<float>() + off[i], s0->device, scenes[i]->b_out_rgb.p, scenes[i]->device, bytes, s0->stream));
+  }
+  std::vector<float> host(total);
+  HIP_TRY(hipMemcpyAsync(host.data(), gather.p, total * 4, hipMemcpyDeviceToHost, s0->stream));
+  HIP_TRY(hipStreamSynchronize(s0->stream));
+  // 3. un-tile into the caller's frame, tone-map once
+  const int W = rp->width, H = rp->height;
+  const int tx = (W + JADE_TILE_SIZE - 1) / JADE_TILE_SIZE;
+  std::vector<float> frame;
+  float* dst_rgb = out_rgb;
+  if (!dst_rgb) {
+    frame.resize((size_t)W * H * 3);
+    dst_rgb = frame.data();
+  }
+  for (int i = 0; i < ndev; ++i) {
+    const jade_scene* s = scenes[i];
+    for (size_t t = 0; t < s->tile_ids.size(); ++t) {
+      int x0 = (s->tile_ids[t] % tx) * JADE_TILE_SIZE, y0 = (s->tile_ids[t] / tx) * JADE_TILE_SIZE;
+      int ww = std::min(JADE_TILE_SIZE, W - x0), hh = std::min(JADE_TILE_SIZE, H - y0);
+      for (int ly = 0; ly < hh; ++ly)
+        memcpy(dst_rgb + ((size_t)(y0 + ly) * W + x0) * 3, host.data() + off[i] + (t * 256 + (size_t)ly * 16) * 3, (size_t)ww * 12);
+    }
+  }
+  if (out_bgr8)
+    for (size_t p = 0; p < (size_t)W * H; ++p) tonemap_pack_host(dst_rgb + 3 * p, JADE_TONEMAP_ACES, 0.0f, out_bgr8 + 3 * p);
+  if (st)
+    for (int i = 0; i < ndev; ++i) {
+      st->rays_primary += sts[i].rays_primary; st->rays_secondary += sts[i].rays_secondary;
+      st->nodes_visited += sts[i].nodes_visited; st->tris_tested += sts[i].tris_tested;
+      st->shaded_hits += sts[i].shaded_hits; st->samples += sts[i].samples;
+      st->kernel_ms = std::max(st->kernel_ms, sts[i].kernel_ms);  // the shares run concurrently
+      st->trace_ms = std::max(st->trace_ms, sts[i].trace_ms);
+      st->trace_launches += sts[i].trace_launches;
+    }
+  return JADE_OK;
 }
 
 int jade_trace_rays(jade_scene* s, int32_t n, const float* origins, const float* dirs, const int32_t* skip, int32_t* hit_index,

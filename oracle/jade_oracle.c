@@ -1051,6 +1051,20 @@ int jade_render(jade_scene* s, const jade_render_params* rp, float* out_rgb, uin
   return jade_render_resolve(s, out_rgb, out_bgr8);
 }
 
+int jade_render_multi(jade_scene* const* scenes, int ndev, const jade_render_params* rp, float* out_rgb, uint8_t* out_bgr8,
+                      jade_stats* st) {
+  /* the CPU oracle has no devices: render the shares one after the other into the same frame */
+  if (!scenes || ndev <= 0 || !rp) return fail(JADE_ERR_INVALID, "null argument");
+  for (int i = 0; i < ndev; ++i) {
+    jade_render_params p = *rp;
+    p.tile_rank = i;
+    p.tile_nranks = ndev;
+    int rc = jade_render(scenes[i], &p, out_rgb, out_bgr8, st);
+    if (rc) return rc;
+  }
+  return JADE_OK;
+}
+
 int jade_render_resolve_tiles_device(jade_scene* s, float* dev_tiles, void* stream) {
   (void)s; (void)dev_tiles; (void)stream;
   return fail(JADE_ERR_UNSUPPORTED, "the CPU oracle has no device buffers");

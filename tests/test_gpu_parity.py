@@ -95,6 +95,25 @@ def test_tile_partition_is_bit_exact(hip):
     assert tot == counters(st_full)
 
 
+def test_render_multi_equals_single_device(hip):
+    """jade_render_multi (one process, one scene per device; here every scene on the one GPU) is
+    bit-identical to jade_render, whatever the number of shares."""
+    hs, cfg = config_scene("tinyjade")
+    p = B.params_from_config(cfg, spp=6)
+    p.width, p.height = 70, 50
+    with hip.scene(hs) as s0:
+        full, full_b, st_full = s0.render(p)
+        for ndev in (1, 2, 3):
+            extra = [hip.scene(hs) for _ in range(ndev - 1)]
+            try:
+                rgb, bgr, st = B.render_multi(hip, [s0] + extra, p)
+            finally:
+                for e in extra:
+                    e.close()
+            assert np.array_equal(rgb.view(np.uint32), full.view(np.uint32)) and np.array_equal(bgr, full_b)
+            assert counters(st) == counters(st_full)
+
+
 def test_progressive_equals_single_call(hip):
     """begin + N x step(spp) + resolve == one render of N*spp (RNG state and sums persist)."""
     hs, cfg = config_scene("tiny")
