@@ -8,6 +8,10 @@ stream, so the image splits into the reference's 16x16 tiles
 statue and a row-major deal degenerates into vertical stripes).  There is no data-path collective while rendering; the only
 exchange is ONE gather of each rank's compact tile buffer to rank 0
 (`torch.distributed.gather`: RCCL over xGMI with backend "nccl", gloo on CPU).
+
+Load order: PyTorch bundles its own HIP runtime.  A process that uses both must import torch and
+initialise CUDA (torch.cuda.init() / set_device) BEFORE the first call into libjade_hip.so; in the
+other order torch finds no GPU.  bench.py does it in that order.
 """
 import numpy as np
 

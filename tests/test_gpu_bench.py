@@ -1,0 +1,44 @@
+"""The driver-facing pieces on the GPU: device-resident tiles for the gather, and bench.py's JSON line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_tiles_feed_the_gather():
+    """jade_render_resolve_tiles_device -> torch tensor -> gather_framebuffer == jade_render_resolve.
+    Runs in a fresh process: PyTorch bundles its own HIP runtime and must initialise it BEFORE
+    libjade_hip.so makes its first HIP call (the other order leaves torch without a GPU)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_tiles_worker.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "tiles ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_bench_json_contract():
+    """One tiny bench run: the single JSON line the driver parses, with roofline and cpu_baseline objects."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "tinyjade", "--width", "96", "--height", "64",
+           "--spp-per-step", "16", "--steps", "2", "--warmup", "1", "--cpu-spp", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "Mray/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 0 and d["frame_ok"] is True
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["achieved"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "Mray/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    # samples rendered in the timed region: 2 steps x 16 spp x 96 x 64 pixels
+    assert d["samples"] == 2 * 16 * 96 * 64
