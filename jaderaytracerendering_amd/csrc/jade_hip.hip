@@ -397,10 +397,11 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
     if (fin) {
       P.hit[(size_t)my_k * npix + my_p] = r.best_index;
       if (r.best_index >= 0) {  // the hit point of a miss is never read
+        const jvec3 hp = ray_hit_point(r, S);
         float* hb = P.hpt + (size_t)my_k * npix + my_p;
-        hb[0] = r.best_point.x;
-        hb[plane] = r.best_point.y;
-        hb[2 * plane] = r.best_point.z;
+        hb[0] = hp.x;
+        hb[plane] = hp.y;
+        hb[2 * plane] = hp.z;
       }
       active = false;
     }

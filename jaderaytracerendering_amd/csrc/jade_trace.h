@@ -104,6 +104,9 @@ static __device__ __forceinline__ bool finite_f(float x) { return (jade_f2u(x) &
 // the current leaf.  Keeping the unit of work small is what lets a 64-lane wave
 // mix lanes that are deep in a leaf with lanes that are still descending
 // without one serialising the other, and lets finished lanes be refilled.
+#ifndef JADE_RECOMPUTE_POINT
+#define JADE_RECOMPUTE_POINT 0
+#endif
 struct RayState {
   jvec3 o, inv, dn;
   int32_t skip;
@@ -113,7 +116,9 @@ struct RayState {
   int sp;
   int32_t best_index;
   float best_dist;
+#if !JADE_RECOMPUTE_POINT
   jvec3 best_point;
+#endif
 };
 
 static __device__ __forceinline__ void ray_begin(RayState& r, const DevScene& S, jvec3 o, jvec3 d, int32_t skip, uint32_t& V) {
@@ -125,7 +130,9 @@ static __device__ __forceinline__ void ray_begin(RayState& r, const DevScene& S,
   r.sp = 0;
   r.best_index = -1;
   r.best_dist = JADE_INF_F;
+#if !JADE_RECOMPUTE_POINT
   r.best_point = jv(0, 0, 0);
+#endif
   r.cur = S.root_ref;
   r.tri_i = r.tri_n = 0;
   if (r.cur & JADE_REF_LEAF) {
@@ -164,6 +171,22 @@ static __device__ __forceinline__ void ray_goto(RayState& r, uint32_t ref) {
 #ifndef JADE_ABLATE_LOAD
 #define JADE_ABLATE_LOAD 0
 #endif
+
+// The hit point of the winning triangle.  With JADE_RECOMPUTE_POINT the three
+// registers of best_point are not carried through the traversal: the point is
+// recomputed once at the end by the same arithmetic on the same operands (same bits).
+static __device__ __forceinline__ jvec3 ray_hit_point(const RayState& r, const DevScene& S) {
+#if JADE_RECOMPUTE_POINT
+  const float4* t0 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.tverts) + (uint32_t)r.best_index * 48u);
+  const float4 a = t0[0], b = t0[1], c = t0[2];
+  float dist;
+  jvec3 P = jv(0, 0, 0);
+  (void)tri_test(jv(a.x, a.y, a.z), jv(b.x, b.y, b.z), jv(c.x, c.y, c.z), r.o, r.dn, &dist, &P);
+  return P;
+#else
+  return r.best_point;
+#endif
+}
 
 // One traversal unit, split by kind so that a wave can run only one kind per
 // iteration (see k_trace).  Both return false when the ray has finished.
@@ -204,7 +227,9 @@ static __device__ __forceinline__ bool ray_step_tri(RayState& r, const DevScene&
       if (tri_test(jv(a0.x, a0.y, a0.z), jv(b0.x, b0.y, b0.z), jv(c0.x, c0.y, c0.z), r.o, r.dn, &dist, &P) && dist < r.best_dist) {
         r.best_index = (int32_t)i;
         r.best_dist = dist;
+#if !JADE_RECOMPUTE_POINT
         r.best_point = P;
+#endif
       }
     }
     if (two && (int32_t)j != r.skip) {
@@ -212,7 +237,9 @@ static __device__ __forceinline__ bool ray_step_tri(RayState& r, const DevScene&
       if (tri_test(jv(a1.x, a1.y, a1.z), jv(b1.x, b1.y, b1.z), jv(c1.x, c1.y, c1.z), r.o, r.dn, &dist, &P) && dist < r.best_dist) {
         r.best_index = (int32_t)j;
         r.best_dist = dist;
+#if !JADE_RECOMPUTE_POINT
         r.best_point = P;
+#endif
       }
     }
     if (r.tri_i < r.tri_n) return true;
