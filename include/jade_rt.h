@@ -32,7 +32,9 @@
 extern "C" {
 #endif
 
-#define JADE_ABI_VERSION 1
+/* bump whenever a struct layout or a documented semantic changes; callers compare
+ * jade_abi_version() with the value they were compiled against */
+#define JADE_ABI_VERSION 2
 
 /* status codes */
 #define JADE_OK 0

@@ -20,6 +20,7 @@ using namespace jadehost;
 
 struct Api {
   void* h = nullptr;
+  int (*abi_version)(void);
   const char* (*backend_name)(void);
   const char* (*last_error)(void);
   int (*scene_create)(const jade_scene_desc*, int, jade_scene**);
@@ -36,12 +37,19 @@ static bool load_api(const std::string& path, Api& a) {
 #define SYM(field, name)                                            \
   *(void**)(&a.field) = dlsym(a.h, name);                           \
   if (!a.field) { fprintf(stderr, "backend lacks %s\n", name); return false; }
+  SYM(abi_version, "jade_abi_version")
   SYM(backend_name, "jade_backend_name")
   SYM(last_error, "jade_last_error")
   SYM(scene_create, "jade_scene_create")
   SYM(scene_destroy, "jade_scene_destroy")
   SYM(render, "jade_render")
 #undef SYM
+  if (a.abi_version() != JADE_ABI_VERSION) {
+    // a stale pair would silently disagree on struct layouts (jade_stats, jade_render_params)
+    fprintf(stderr, "backend %s speaks jade_rt ABI %d, this program was built against %d: rebuild both (make)\n", path.c_str(),
+            a.abi_version(), JADE_ABI_VERSION);
+    return false;
+  }
   return true;
 }
 

@@ -102,3 +102,12 @@ def test_scene_validation_errors(which, oracle):
         ni[n, 0], ni[n, 1] = n + 1, 2 * n + 1
         s.a["nodes"] = nodes
     expect(deep_chain, (_abi.JADE_ERR_UNSUPPORTED,))
+
+
+def test_abi_version_is_single_sourced():
+    """include/jade_rt.h, the Python mirror and both libraries agree (a stale binary must not pass)."""
+    text = open(os.path.join(ROOT, "include", "jade_rt.h")).read()
+    ver = int(re.search(r"#define JADE_ABI_VERSION (\d+)", text).group(1))
+    assert ver == _abi.JADE_ABI_VERSION
+    for path in (B.HIP_LIB, os.path.join(ROOT, "oracle", "libjade_oracle.so")):
+        assert ctypes.CDLL(path).jade_abi_version() == ver, path

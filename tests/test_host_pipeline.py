@@ -259,8 +259,7 @@ def test_cli_renders_with_the_oracle_backend(tmp_path):
     import subprocess
     from conftest import ORACLE_LIB, ROOT
     exe = os.path.join(ROOT, "jaderaytracerendering_amd", "lib", "jade_render")
-    if not os.path.exists(exe):
-        subprocess.check_call(["make", "-C", ROOT, "cli"])
+    subprocess.check_call(["make", "-s", "-C", ROOT, "cli"])   # make rebuilds it iff a header or source changed
     out = tmp_path / "o.bmp"
     r = subprocess.run([exe, "--config", "tiny", "--backend", ORACLE_LIB, "--out", str(out)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
