@@ -8,7 +8,10 @@ CXX      ?= g++
 # -ffp-contract=off everywhere: include/jade_fpmath.h pins the evaluation order.
 FPFLAGS  := -ffp-contract=off -fno-fast-math
 CXXFLAGS := -O2 -g -std=c++17 -fPIC -mfma $(FPFLAGS) -Wall -Wextra -Wno-unused-parameter -I$(ROOT)/include -I$(PKG)/host
-HIPFLAGS := $(HIPDEFS) -O3 -std=c++17 -fPIC --offload-arch=gfx950 $(FPFLAGS) -fhip-fp32-correctly-rounded-divide-sqrt \
+# -fno-slp-vectorize: packed fp32 pairs (v_pk_*_f32) need aligned register pairs and copies; without them
+# k_trace fits 60 VGPRs (8 waves/SIMD) instead of 70, and the kernel is latency-bound, not VALU-bound.
+HIPVEC   ?= -fno-slp-vectorize
+HIPFLAGS := $(HIPDEFS) -O3 $(HIPVEC) -std=c++17 -fPIC --offload-arch=gfx950 $(FPFLAGS) -fhip-fp32-correctly-rounded-divide-sqrt \
             -fno-gpu-flush-denormals-to-zero -mfma -Wall -Wno-unused-parameter -I$(ROOT)/include -I$(PKG)/csrc
 
 HOST_SRC := $(PKG)/host/scene_build.cpp $(PKG)/host/scene_io.cpp $(PKG)/host/host_capi.cpp

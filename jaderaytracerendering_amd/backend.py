@@ -159,7 +159,8 @@ def hip():
     """The product backend.  Fails loudly if the HIP extension was not built."""
     global _hip
     if _hip is None:
-        _hip = Backend(HIP_LIB)
+        # JADE_HIP_LIB points development tools at another BUILD of the same HIP library (A/B runs)
+        _hip = Backend(os.environ.get("JADE_HIP_LIB", HIP_LIB))
     return _hip
 
 

@@ -31,11 +31,10 @@
 #define JADE_INF_F 2147483647.0f /* #define INF, PathTrace.cu:23 */
 
 #ifndef JADE_LDS_STACK
-#define JADE_LDS_STACK 24 /* traversal stack entries kept in LDS per lane: 24 KB/block -> 6 blocks/CU */
+#define JADE_LDS_STACK 12 /* traversal stack entries kept in LDS per lane; deeper ones spill to global.  The deepest \
+                             stack of any ray is 12 on C3 and C5 (tools/ray_histogram.py): 99.97 % need <= 10 */
 #endif
-#ifndef JADE_TRIS_PER_STEP
-#define JADE_TRIS_PER_STEP 1 /* triangle tests per traversal unit (1 or 2); 2 costs 38 VGPRs = 2 waves/SIMD */
-#endif
+#define JADE_LDS_STATE 8  /* ray-state words kept in the same LDS column (jade_trace.h): 20 words * 256 lanes = 20 KB/block, 8 blocks/CU */
 #define JADE_TRACE_BLOCK 256
 #define JADE_RECORD_BUDGET (72ll << 20) /* path records kept in flight per GPU (~250 B each) */
 
@@ -136,18 +135,6 @@ struct DevCounters {
 #define JADE_TRACE_CHUNK 512 /* most rays a wave claims per queue atomic */
 #endif
 #define JADE_REFILL_MIN 16    /* idle lanes in a wave that trigger a refill */
-#ifndef JADE_PHASED
-#define JADE_PHASED 0       /* 1: run one kind of traversal unit per wave iteration (measured slower: 2067 vs 2214 Mray/s) */
-#endif
-#ifndef JADE_COST_NODE
-#define JADE_COST_NODE 60   /* relative issue cost of a node visit ... */
-#endif
-#ifndef JADE_COST_TRI
-#define JADE_COST_TRI 130   /* ... and of a triangle test */
-#endif
-#ifndef JADE_STEPS_PER_CHECK
-#define JADE_STEPS_PER_CHECK 1 /* traversal units between two refill checks (more costs 30 VGPRs) */
-#endif
 
 static __device__ __forceinline__ jvec3 ld3(const float* a, int npix, int p) {
   return jv(a[p], a[npix + p], a[2 * npix + p]);

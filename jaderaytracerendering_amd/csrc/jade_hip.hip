@@ -30,10 +30,10 @@
 
 // ------------------------------------------------------------------ kernels --
 
-struct QueueCtl {
-  uint32_t count;   // rays emitted by the last shade pass
+struct alignas(8) QueueCtl {
+  uint32_t count;   // rays emitted by the last shade pass          } one 64-bit word: k_shade reserves its queue
+  uint32_t active;  // records with rays in flight after that pass } and list space with ONE atomic per block
   uint32_t next;    // next unclaimed queue entry (trace)
-  uint32_t active;  // records with rays in flight after the last shade pass
   uint32_t fp_bad;  // jade_fp_selftest result (checked once)
 };
 
@@ -128,6 +128,7 @@ __global__ __launch_bounds__(JADE_SHADE_BLOCK, JADE_SHADE_WAVES) void k_shade(De
                                                uint32_t target_spp, const uint32_t* active_in, uint32_t n_active,
                                                uint32_t* active_out, uint32_t* queue, QueueCtl* qc, DevCounters* ctr) {
   __shared__ uint32_t sh_rays[JADE_SHADE_NW], sh_act[JADE_SHADE_NW], sh_base[2];
+  __shared__ uint32_t sh_ctr[JADE_SHADE_NW][4];
   const uint32_t t_idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int npix = P.npix;
   const int p = t_idx < n_active ? (int)active_in[t_idx] : npix;
@@ -293,8 +294,11 @@ __global__ __launch_bounds__(JADE_SHADE_BLOCK, JADE_SHADE_WAVES) void k_shade(De
       tr += sh_rays[i];
       ta += sh_act[i];
     }
-    sh_base[0] = tr ? atomicAdd(&qc->count, tr) : 0u;
-    sh_base[1] = ta ? atomicAdd(&qc->active, ta) : 0u;
+    // count can never carry into active: a pass emits < 2^32 rays (nslots * npix < 2^32 is checked in jade_render_begin)
+    const unsigned long long got =
+        (tr | ta) ? atomicAdd(reinterpret_cast<unsigned long long*>(&qc->count), (unsigned long long)tr | ((unsigned long long)ta << 32)) : 0ull;
+    sh_base[0] = (uint32_t)got;
+    sh_base[1] = (uint32_t)(got >> 32);
   }
   __syncthreads();
   if (live) {
@@ -308,14 +312,22 @@ __global__ __launch_bounds__(JADE_SHADE_BLOCK, JADE_SHADE_WAVES) void k_shade(De
     for (int k = 0; k < used; ++k)
       if (P.hit[(size_t)k * npix + p] == -1) queue[wq++] = (uint32_t)k * (uint32_t)npix + (uint32_t)p;
   }
-  unsigned long long s0 = wave_sum_u32(c.c_primary), s1 = wave_sum_u32(c.c_secondary), s2 = wave_sum_u32(c.c_shaded),
-                     s3 = wave_sum_u32(c.c_samples);
+  // work counters: per wave into LDS, then one set of atomics per block
+  const uint32_t s0 = (uint32_t)wave_sum_u32(c.c_primary), s1 = (uint32_t)wave_sum_u32(c.c_secondary),
+                 s2 = (uint32_t)wave_sum_u32(c.c_shaded), s3 = (uint32_t)wave_sum_u32(c.c_samples);
   if (lane == 0) {
+    sh_ctr[w][0] = s0;
+    sh_ctr[w][1] = s1;
+    sh_ctr[w][2] = s2;
+    sh_ctr[w][3] = s3;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    unsigned long long t = 0;
+    for (int i = 0; i < JADE_SHADE_NW; ++i) t += sh_ctr[i][threadIdx.x];
     DevCounters* cs = ctr + (blockIdx.x % JADE_CTR_SHARDS);
-    if (s0) atomicAdd(&cs->rays_primary, s0);
-    if (s1) atomicAdd(&cs->rays_secondary, s1);
-    if (s2) atomicAdd(&cs->shaded_hits, s2);
-    if (s3) atomicAdd(&cs->samples, s3);
+    unsigned long long* dst = threadIdx.x == 0 ? &cs->rays_primary : threadIdx.x == 1 ? &cs->rays_secondary : threadIdx.x == 2 ? &cs->shaded_hits : &cs->samples;
+    if (t) atomicAdd(dst, t);
   }
 }
 
@@ -324,23 +336,22 @@ __global__ __launch_bounds__(JADE_SHADE_BLOCK, JADE_SHADE_WAVES) void k_shade(De
 #endif
 __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(DevScene S, PathState P, const uint32_t* queue, QueueCtl* qc,
                                                            uint32_t* spill, DevCounters* ctr, uint32_t chunk) {
-  __shared__ uint32_t lds_stack[JADE_LDS_STACK * JADE_TRACE_BLOCK];
+  __shared__ uint32_t lds_cols[(JADE_LDS_STACK + JADE_LDS_STATE) * JADE_TRACE_BLOCK];
   const int lane = threadIdx.x & 63;
   const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
   LdsStack stk;
-  stk.lds = lds_stack + threadIdx.x;
-  stk.stride_lds = JADE_TRACE_BLOCK;
+  stk.lds = lds_cols + threadIdx.x;
   stk.spill = spill + gtid;
   stk.stride_spill = gridDim.x * blockDim.x;
   const uint32_t n = qc->count;
   const int npix = P.npix;
   const size_t plane = (size_t)P.nslots * npix;
-  uint32_t V = 0, T = 0;
+  uint32_t V = 0, T = 0;  // wave totals (uniform: they live in SGPRs)
   // wave-local chunk of the queue: [lbase, lend) (wave-uniform)
   uint32_t lbase = 0, lend = 0;
   bool queue_empty = false;
   bool active = false;
-  uint32_t my_k = 0, my_p = 0;
+  uint32_t my_e = 0;  // this lane's queue entry: slot * npix + record
   RayState r;
   for (;;) {
     // ---- refill idle lanes once enough of them are idle (or all are)
@@ -363,42 +374,32 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
       const uint32_t take = (uint32_t)n_idle < avail ? (uint32_t)n_idle : avail;
       const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
       if (!active && rank < take) {
-        const uint32_t e = queue[lbase + rank];
-        my_k = e / (uint32_t)npix;
-        my_p = e - my_k * (uint32_t)npix;
-        const jvec3 o = ld3(P.org, npix, my_p);
-        const float* db = P.dir + (size_t)my_k * npix + my_p;
+        my_e = queue[lbase + rank];
+        const uint32_t k = my_e / (uint32_t)npix, p = my_e - k * (uint32_t)npix;
+        const jvec3 o = ld3(P.org, npix, p);
+        const float* db = P.dir + my_e;
         const jvec3 d = jv(db[0], db[plane], db[2 * plane]);
-        ray_begin(r, S, o, d, P.skip[my_p], V);
+        ray_begin(r, stk, S, o, d, P.skip[p]);
         active = true;
       }
+      V += take;  // the root record of every ray started
       lbase += take;
     }
     if (n_idle == 64 && queue_empty) break;  // nothing in flight, nothing left to claim
-    // ---- one traversal unit per lane, ONE kind per iteration: a node visit costs
-    // about JADE_COST_NODE instructions and a triangle test JADE_COST_TRI, and running
-    // both kinds back to back with half the lanes masked in each wastes issue slots, so
-    // the wave runs whichever kind advances more lanes per instruction; the others wait
-    // (they become the majority soon enough: no lane can starve).
-    bool fin = false;
-#if JADE_PHASED
-    {
-      const bool wt = active && ray_wants_tri(r);
-      const int nt = __popcll(__ballot(wt)), nn = __popcll(__ballot(active && !wt));
-      if (JADE_COST_TRI * nn >= JADE_COST_NODE * nt) {
-        if (active && !wt) fin = !ray_step_node(r, S, stk, V);
-      } else {
-        if (wt) fin = !ray_step_tri(r, S, stk, T);
-      }
+    // ---- one traversal unit per lane
+    bool fin = false, c1 = false, c2 = false, tested = false;
+    if (active) {
+      if (ray_in_leaf(r)) fin = !ray_step_tri(r, S, stk, &tested);
+      else fin = !ray_step_node(r, S, stk, &c1, &c2);
     }
-#else
-    if (active) fin = !ray_step(r, S, stk, V, T);
-#endif
+    V += (uint32_t)__popcll(__ballot(c1)) + (uint32_t)__popcll(__ballot(c2));
+    T += (uint32_t)__popcll(__ballot(tested));
     if (fin) {
-      P.hit[(size_t)my_k * npix + my_p] = r.best_index;
-      if (r.best_index >= 0) {  // the hit point of a miss is never read
-        const jvec3 hp = ray_hit_point(r, S);
-        float* hb = P.hpt + (size_t)my_k * npix + my_p;
+      const int32_t best = ray_best_index(stk);
+      P.hit[my_e] = best;
+      if (best >= 0) {  // the hit point of a miss is never read
+        const jvec3 hp = ray_hit_point(stk);
+        float* hb = P.hpt + my_e;
         hb[0] = hp.x;
         hb[plane] = hp.y;
         hb[2 * plane] = hp.z;
@@ -406,11 +407,10 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
       active = false;
     }
   }
-  unsigned long long sv = wave_sum_u32(V), stt = wave_sum_u32(T);
   if (lane == 0) {
     DevCounters* cs = ctr + (blockIdx.x % JADE_CTR_SHARDS);
-    if (sv) atomicAdd(&cs->nodes_visited, sv);
-    if (stt) atomicAdd(&cs->tris_tested, stt);
+    if (V) atomicAdd(&cs->nodes_visited, (unsigned long long)V);
+    if (T) atomicAdd(&cs->tris_tested, (unsigned long long)T);
   }
 }
 
@@ -676,13 +676,14 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
     delete s;
     return fail(JADE_ERR_DEVICE, m);
   }
-  // persistent trace grid: blocks per CU bounded by the LDS stack (32 KB/block)
+  // persistent trace grid: as many blocks per CU as registers and the LDS columns (20 KB/block) allow
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device_id));
   int per_cu = 0;
   (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace, JADE_TRACE_BLOCK, 0);
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 8) per_cu = 8;
+  if (getenv("JADE_LOG_PASSES")) fprintf(stderr, "[jade] k_trace: %d blocks of %d threads per CU, %d CUs\n", per_cu, JADE_TRACE_BLOCK, prop.multiProcessorCount);
   s->trace_blocks = prop.multiProcessorCount * per_cu;
   *out = s;
   return JADE_OK;
@@ -820,7 +821,7 @@ static int run_passes(jade_scene* s, uint32_t target_spp, double* ms_out, double
                      s->b_active[0].as<uint32_t>(), qc);
   HIP_TRY(hipMemcpyAsync(host_ctl, qc, 12, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
-  uint32_t n_active = host_ctl[2];
+  uint32_t n_active = host_ctl[1];
   int cur = 0, pass_no = 0;
   const bool log_passes = getenv("JADE_LOG_PASSES") != nullptr;
   hipEvent_t sa, sb;
@@ -844,7 +845,7 @@ static int run_passes(jade_scene* s, uint32_t target_spp, double* ms_out, double
       launches += 1;
       trace_pending = false;
     }
-    n_active = host_ctl[2];
+    n_active = host_ctl[1];
     cur ^= 1;
     if (host_ctl[0] == 0) break;
     HIP_TRY(hipEventRecord(ta, s->stream));
@@ -1121,7 +1122,7 @@ int jade_trace_rays(jade_scene* s, int32_t n, const float* origins, const float*
   P.hit = b_hit.as<int32_t>(); P.hpt = b_hpt.as<float>();
   QueueCtl qc{};
   qc.count = (uint32_t)n;
-  HIP_TRY(hipMemcpy(s->b_ctl.p, &qc, 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(s->b_ctl.p, &qc, 12, hipMemcpyHostToDevice));  // count, active, next
   HIP_TRY(hipMemset(s->b_ctr.p, 0, sizeof(DevCounters) * JADE_CTR_SHARDS));
   hipEvent_t ev0, ev1;
   HIP_TRY(hipEventCreate(&ev0));

@@ -18,8 +18,13 @@
 //     which visits nodes in exactly the reference's order with half the stack
 //     traffic;
 //   - the stack lives in LDS as stack[level][lane] (bank-conflict free: lane
-//     l always hits bank l % 32 of its half-wave), deeper levels spill to a
-//     per-lane global area (JADE_BVH_STACK_CAPACITY entries in total);
+//     l always hits bank l % 32 of its half-wave); 12 levels cover every ray of
+//     the benchmark scenes, deeper levels spill to a per-lane global area
+//     (JADE_BVH_STACK_CAPACITY entries in total);
+//   - the parts of the ray state that the triangle test does not read (1/dir,
+//     the best hit so far) live in the same LDS column, so the kernel needs 60
+//     VGPRs and a SIMD holds 8 waves: the kernel is latency-bound, waves are
+//     what hides the latency;
 //   - both children's boxes come from the parent's 64-B record, so a node
 //     visit is four 16-B loads of one line (see jade_device.h);
 //   - 1/dir and normalize(dir), which the reference recomputes per node and
@@ -33,19 +38,28 @@ struct TraceHit {
   jvec3 point;
 };
 
+// A lane's column of LDS words, lds[word * JADE_TRACE_BLOCK + tid] (bank-conflict free):
+// words [0, JADE_LDS_STACK) are the traversal stack, the JADE_LDS_STATE words after it hold
+// the parts of the ray state that the triangle test does not read (see RayState).
 struct LdsStack {
-  uint32_t* lds;       // base of this lane's column: lds[level * blockDim + tid]
+  uint32_t* lds;       // base of this lane's column
   uint32_t* spill;     // global, spill[(level - JADE_LDS_STACK) * stride + gtid]
-  uint32_t stride_lds;
   uint32_t stride_spill;
 };
+enum { LW_INVX = JADE_LDS_STACK, LW_INVY, LW_INVZ, LW_BEST_DIST, LW_BEST_INDEX, LW_PX, LW_PY, LW_PZ, LW_END };
+static_assert(LW_END - JADE_LDS_STACK == JADE_LDS_STATE, "JADE_LDS_STATE must count the LW_* state words");
+
+static __device__ __forceinline__ void lds_put(const LdsStack& s, int word, uint32_t v) { s.lds[word * JADE_TRACE_BLOCK] = v; }
+static __device__ __forceinline__ uint32_t lds_get(const LdsStack& s, int word) { return s.lds[word * JADE_TRACE_BLOCK]; }
+static __device__ __forceinline__ void lds_putf(const LdsStack& s, int word, float v) { lds_put(s, word, jade_f2u(v)); }
+static __device__ __forceinline__ float lds_getf(const LdsStack& s, int word) { return jade_u2f(lds_get(s, word)); }
 
 static __device__ __forceinline__ void stack_push(const LdsStack& s, int sp, uint32_t v) {
-  if (sp < JADE_LDS_STACK) s.lds[sp * s.stride_lds] = v;
+  if (sp < JADE_LDS_STACK) s.lds[sp * JADE_TRACE_BLOCK] = v;
   else s.spill[(size_t)(sp - JADE_LDS_STACK) * s.stride_spill] = v;
 }
 static __device__ __forceinline__ uint32_t stack_pop(const LdsStack& s, int sp) {
-  if (sp < JADE_LDS_STACK) return s.lds[sp * s.stride_lds];
+  if (sp < JADE_LDS_STACK) return s.lds[sp * JADE_TRACE_BLOCK];
   return s.spill[(size_t)(sp - JADE_LDS_STACK) * s.stride_spill];
 }
 
@@ -98,66 +112,47 @@ static __device__ __forceinline__ bool tri_test(jvec3 p1, jvec3 p2, jvec3 p3, jv
 
 static __device__ __forceinline__ bool finite_f(float x) { return (jade_f2u(x) & 0x7f800000u) != 0x7f800000u; }
 
-// One lane's traversal state for hitBVH (PathTrace.cu:795-859), advanced one
-// small unit per call: either one internal-node visit (both children's slab
-// tests, near-first descent, far child pushed) or up to two triangle tests of
-// the current leaf.  Keeping the unit of work small is what lets a 64-lane wave
-// mix lanes that are deep in a leaf with lanes that are still descending
-// without one serialising the other, and lets finished lanes be refilled.
-#ifndef JADE_RECOMPUTE_POINT
-#define JADE_RECOMPUTE_POINT 0
-#endif
+// One lane's traversal state for hitBVH (PathTrace.cu:795-859), advanced one small unit per
+// call: either one internal-node visit (both children's slab tests, near-first descent, far
+// child pushed) or one triangle test of the current leaf.  Keeping the unit of work small is
+// what lets a 64-lane wave mix lanes that are deep in a leaf with lanes that are still
+// descending without one serialising the other, and lets finished lanes be refilled.
+//
+// The kernel is latency-bound, so what matters is how many waves a SIMD holds: the state is cut
+// to what fits 64 VGPRs (8 waves).  In registers: o, normalize(d), the skip index, the
+// cursor and the stack pointer.  In the lane's LDS column: 1/d (read by node visits only) and
+// the best hit so far (touched only when a triangle is actually hit).  The leaf cursor IS the
+// leaf reference: LEAF | first << 4 | count, advanced by +15 per triangle (first + 1, count - 1).
+struct V3ld {
+  float x, y, z;
+};
 struct RayState {
-  jvec3 o, inv, dn;
-  int32_t skip;
-  bool exact;
-  uint32_t cur;          // current ref (internal node or leaf)
-  uint32_t tri_i, tri_n; // leaf cursor: next triangle, end (tri_i < tri_n while inside a leaf)
+  jvec3 o, dn;
+  uint32_t skipx;  // bit 31: a component of o or 1/d is not finite (NaN-faithful slab needed); bits 0-30: source triangle, 0x7fffffff = none
+  uint32_t cur;    // internal-node ref, or leaf cursor
   int sp;
-  int32_t best_index;
-  float best_dist;
-#if !JADE_RECOMPUTE_POINT
-  jvec3 best_point;
-#endif
 };
 
-static __device__ __forceinline__ void ray_begin(RayState& r, const DevScene& S, jvec3 o, jvec3 d, int32_t skip, uint32_t& V) {
+static __device__ __forceinline__ void ray_begin(RayState& r, const LdsStack& stk, const DevScene& S, jvec3 o, jvec3 d, int32_t skip) {
   r.o = o;
-  r.inv = jv(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  const jvec3 inv = jv(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
   r.dn = jv_normalize(d);
-  r.skip = skip;
-  r.exact = !(finite_f(r.inv.x) && finite_f(r.inv.y) && finite_f(r.inv.z)) || !finite_f(o.x) || !finite_f(o.y) || !finite_f(o.z);
+  const bool exact = !(finite_f(inv.x) && finite_f(inv.y) && finite_f(inv.z)) || !finite_f(o.x) || !finite_f(o.y) || !finite_f(o.z);
+  r.skipx = (skip < 0 ? 0x7fffffffu : (uint32_t)skip) | (exact ? 0x80000000u : 0u);
   r.sp = 0;
-  r.best_index = -1;
-  r.best_dist = JADE_INF_F;
-#if !JADE_RECOMPUTE_POINT
-  r.best_point = jv(0, 0, 0);
-#endif
   r.cur = S.root_ref;
-  r.tri_i = r.tri_n = 0;
-  if (r.cur & JADE_REF_LEAF) {
-    r.tri_i = (r.cur & 0x7fffffffu) >> 4;
-    r.tri_n = r.tri_i + (r.cur & 15u);
-  }
-  V += 1;  // the root record
+  lds_putf(stk, LW_INVX, inv.x);
+  lds_putf(stk, LW_INVY, inv.y);
+  lds_putf(stk, LW_INVZ, inv.z);
+  lds_putf(stk, LW_BEST_DIST, JADE_INF_F);
+  lds_put(stk, LW_BEST_INDEX, 0xffffffffu);
 }
 
-// Make `ref` current; returns false when the stack is empty (ray finished).
+// Make the top of the stack current; returns false when the stack is empty (ray finished).
 static __device__ __forceinline__ bool ray_pop(RayState& r, const LdsStack& stk) {
   if (r.sp == 0) return false;
   r.cur = stack_pop(stk, --r.sp);
-  if (r.cur & JADE_REF_LEAF) {
-    r.tri_i = (r.cur & 0x7fffffffu) >> 4;
-    r.tri_n = r.tri_i + (r.cur & 15u);
-  }
   return true;
-}
-static __device__ __forceinline__ void ray_goto(RayState& r, uint32_t ref) {
-  r.cur = ref;
-  if (ref & JADE_REF_LEAF) {
-    r.tri_i = (ref & 0x7fffffffu) >> 4;
-    r.tri_n = r.tri_i + (ref & 15u);
-  }
 }
 
 // Development ablations (cdna_hip_programming.md rule 17): JADE_ABLATE_* repeat a
@@ -168,43 +163,25 @@ static __device__ __forceinline__ void ray_goto(RayState& r, uint32_t ref) {
 #ifndef JADE_ABLATE_SLAB
 #define JADE_ABLATE_SLAB 0
 #endif
-#ifndef JADE_ABLATE_LOAD
-#define JADE_ABLATE_LOAD 0
-#endif
 
-// The hit point of the winning triangle.  With JADE_RECOMPUTE_POINT the three
-// registers of best_point are not carried through the traversal: the point is
-// recomputed once at the end by the same arithmetic on the same operands (same bits).
-static __device__ __forceinline__ jvec3 ray_hit_point(const RayState& r, const DevScene& S) {
-#if JADE_RECOMPUTE_POINT
-  const float4* t0 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.tverts) + (uint32_t)r.best_index * 48u);
-  const float4 a = t0[0], b = t0[1], c = t0[2];
-  float dist;
-  jvec3 P = jv(0, 0, 0);
-  (void)tri_test(jv(a.x, a.y, a.z), jv(b.x, b.y, b.z), jv(c.x, c.y, c.z), r.o, r.dn, &dist, &P);
-  return P;
-#else
-  return r.best_point;
-#endif
+static __device__ __forceinline__ int32_t ray_best_index(const LdsStack& stk) { return (int32_t)lds_get(stk, LW_BEST_INDEX); }
+static __device__ __forceinline__ jvec3 ray_hit_point(const LdsStack& stk) {
+  return jv(lds_getf(stk, LW_PX), lds_getf(stk, LW_PY), lds_getf(stk, LW_PZ));
 }
 
-// One traversal unit, split by kind so that a wave can run only one kind per
-// iteration (see k_trace).  Both return false when the ray has finished.
-static __device__ __forceinline__ bool ray_wants_tri(const RayState& r) { return r.tri_i < r.tri_n; }
+static __device__ __forceinline__ bool ray_in_leaf(const RayState& r) { return (r.cur & JADE_REF_LEAF) != 0; }
 
-static __device__ __forceinline__ bool ray_step_tri(RayState& r, const DevScene& S, const LdsStack& stk, uint32_t& T) {
-    // ---- up to two triangles of the current leaf (hitArray, PathTrace.cu:776-792),
-    // tested in index order; both vertex records are requested before either is used
-    const uint32_t i = r.tri_i;
-    const bool two = JADE_TRIS_PER_STEP > 1 && i + 1 < r.tri_n;
-    const uint32_t j = two ? i + 1 : i;
+// One triangle of the current leaf (hitArray, PathTrace.cu:776-792), in index order.
+// *tested: this lane ran an intersection test (the skipped source triangle does not count).
+static __device__ __forceinline__ bool ray_step_tri(RayState& r, const DevScene& S, const LdsStack& stk, bool* tested) {
+  if (r.cur & 15u) {
+    const uint32_t i = (r.cur & 0x7fffffffu) >> 4;
     // 32-bit byte offsets from a scalar base (n_tris < 2^27: 48 B * i fits): saddr + voffset loads
-    const char* tb = reinterpret_cast<const char*>(S.tverts);
-    const float4* t0 = reinterpret_cast<const float4*>(tb + i * 48u);
-    const float4* t1 = reinterpret_cast<const float4*>(tb + j * 48u);
-    const float4 a0 = t0[0], b0 = t0[1], c0 = t0[2];
-    const float4 a1 = t1[0], b1 = t1[1], c1 = t1[2];
-    r.tri_i = j + 1;
+    // (three 12-B loads: the pad word of each vertex is never brought into a register)
+    const char* t0 = reinterpret_cast<const char*>(S.tverts) + i * 48u;
+    const V3ld a0 = *reinterpret_cast<const V3ld*>(t0), b0 = *reinterpret_cast<const V3ld*>(t0 + 16),
+               c0 = *reinterpret_cast<const V3ld*>(t0 + 32);
+    r.cur += 15u;  // first + 1, count - 1
     float dist;
     jvec3 P;
 #if JADE_ABLATE_TRI
@@ -215,88 +192,62 @@ static __device__ __forceinline__ bool ray_step_tri(RayState& r, const DevScene&
       asm volatile("" ::"v"(h2 ? d2 + P2.x : 0.0f));
     }
 #endif
-#if JADE_ABLATE_LOAD
-    {
-      const float4 x = S.tverts[3 * (size_t)i];
-      const float4 y = S.tverts[3 * (size_t)(__float_as_uint(x.w) & 1u)];  // dependent on the first
-      asm volatile("" ::"v"(y.x));
-    }
-#endif
-    if ((int32_t)i != r.skip) {
-      T += 1;
-      if (tri_test(jv(a0.x, a0.y, a0.z), jv(b0.x, b0.y, b0.z), jv(c0.x, c0.y, c0.z), r.o, r.dn, &dist, &P) && dist < r.best_dist) {
-        r.best_index = (int32_t)i;
-        r.best_dist = dist;
-#if !JADE_RECOMPUTE_POINT
-        r.best_point = P;
-#endif
+    if (i != (r.skipx & 0x7fffffffu)) {
+      *tested = true;
+      if (tri_test(jv(a0.x, a0.y, a0.z), jv(b0.x, b0.y, b0.z), jv(c0.x, c0.y, c0.z), r.o, r.dn, &dist, &P) &&
+          dist < lds_getf(stk, LW_BEST_DIST)) {
+        lds_putf(stk, LW_BEST_DIST, dist);
+        lds_put(stk, LW_BEST_INDEX, i);
+        lds_putf(stk, LW_PX, P.x);
+        lds_putf(stk, LW_PY, P.y);
+        lds_putf(stk, LW_PZ, P.z);
       }
     }
-    if (two && (int32_t)j != r.skip) {
-      T += 1;
-      if (tri_test(jv(a1.x, a1.y, a1.z), jv(b1.x, b1.y, b1.z), jv(c1.x, c1.y, c1.z), r.o, r.dn, &dist, &P) && dist < r.best_dist) {
-        r.best_index = (int32_t)j;
-        r.best_dist = dist;
-#if !JADE_RECOMPUTE_POINT
-        r.best_point = P;
-#endif
-      }
-    }
-    if (r.tri_i < r.tri_n) return true;
-    return ray_pop(r, stk);
+  }
+  if (r.cur & 15u) return true;
+  return ray_pop(r, stk);  // leaf finished (or empty: cannot happen for a valid BVH)
 }
 
-static __device__ __forceinline__ bool ray_step_node(RayState& r, const DevScene& S, const LdsStack& stk, uint32_t& V) {
-  if (r.cur & JADE_REF_LEAF) return ray_pop(r, stk);  // empty leaf (cannot happen for a valid BVH)
-  // ---- one internal node
+// One internal node.  *c1, *c2: the child exists (its record counts as visited).
+static __device__ __forceinline__ bool ray_step_node(RayState& r, const DevScene& S, const LdsStack& stk, bool* c1, bool* c2) {
   const float4* nd = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.nodes) + r.cur * 64u);
   const float4 a = nd[0], b = nd[1], c = nd[2];
-  const uint4 rf = *reinterpret_cast<const uint4*>(nd + 3);
+  const uint2 rf = *reinterpret_cast<const uint2*>(nd + 3);
+  const jvec3 inv = jv(lds_getf(stk, LW_INVX), lds_getf(stk, LW_INVY), lds_getf(stk, LW_INVZ));
+  const bool exact = (int32_t)r.skipx < 0;
   float d1 = -1.0f, d2 = -1.0f;
 #if JADE_ABLATE_SLAB
   {
     jvec3 o2 = jv(r.o.x + 1e-30f, r.o.y, r.o.z);
-    float e1 = slab(o2, r.inv, a.x, a.y, a.z, a.w, b.x, b.y, r.exact), e2 = slab(o2, r.inv, b.z, b.w, c.x, c.y, c.z, c.w, r.exact);
+    float e1 = slab(o2, inv, a.x, a.y, a.z, a.w, b.x, b.y, exact), e2 = slab(o2, inv, b.z, b.w, c.x, c.y, c.z, c.w, exact);
     asm volatile("" ::"v"(e1 + e2));
   }
 #endif
-#if JADE_ABLATE_LOAD
-  {
-    const float4 y = S.nodes[4 * (size_t)(rf.x & 1u)];  // dependent on this node's record
-    asm volatile("" ::"v"(y.x));
-  }
-#endif
   if (rf.x != JADE_REF_NONE) {
-    V += 1;
-    d1 = slab(r.o, r.inv, a.x, a.y, a.z, a.w, b.x, b.y, r.exact);
+    *c1 = true;
+    d1 = slab(r.o, inv, a.x, a.y, a.z, a.w, b.x, b.y, exact);
   }
   if (rf.y != JADE_REF_NONE) {
-    V += 1;
-    d2 = slab(r.o, r.inv, b.z, b.w, c.x, c.y, c.z, c.w, r.exact);
+    *c2 = true;
+    d2 = slab(r.o, inv, b.z, b.w, c.x, c.y, c.z, c.w, exact);
   }
   if (d1 > 0 && d2 > 0) {
     if (d1 < d2) {
       stack_push(stk, r.sp++, rf.y);
-      ray_goto(r, rf.x);
+      r.cur = rf.x;
     } else {
       stack_push(stk, r.sp++, rf.x);
-      ray_goto(r, rf.y);
+      r.cur = rf.y;
     }
     return true;
   }
   if (d1 > 0) {
-    ray_goto(r, rf.x);
+    r.cur = rf.x;
     return true;
   }
   if (d2 > 0) {
-    ray_goto(r, rf.y);
+    r.cur = rf.y;
     return true;
   }
   return ray_pop(r, stk);
-}
-
-// Returns false when the ray has finished.
-static __device__ __forceinline__ bool ray_step(RayState& r, const DevScene& S, const LdsStack& stk, uint32_t& V, uint32_t& T) {
-  if (ray_wants_tri(r)) return ray_step_tri(r, S, stk, T);
-  return ray_step_node(r, S, stk, V);
 }

@@ -176,8 +176,15 @@ static HitResult hit_array(const jade_scene* s, Ray ray, int l, int r, int src_o
 }
 
 /* Diagnostics only (not part of jade_rt.h): histogram of node pops + triangle
- * tests per hitBVH call in log2 buckets, read by tools/ray_histogram.py. */
+ * tests per hitBVH call in log2 buckets, and (jade_oracle_stack_histogram) the deepest
+ * number of deferred far children per call, linear buckets: what sizes the HIP
+ * kernel's LDS stack (tools/ray_histogram.py). */
 static uint64_t g_visit_hist[2][32];
+static uint64_t g_stack_hist[64];
+void jade_oracle_stack_histogram(uint64_t* out, int reset) {
+  memcpy(out, g_stack_hist, sizeof g_stack_hist);
+  if (reset) memset(g_stack_hist, 0, sizeof g_stack_hist);
+}
 void jade_oracle_visit_histogram(uint64_t* out, int reset) {
   memcpy(out, g_visit_hist, sizeof g_visit_hist);
   if (reset) memset(g_visit_hist, 0, sizeof g_visit_hist);
@@ -202,7 +209,9 @@ static HitResult hit_bvh(const jade_scene* s, Ray ray, int src_object_idx, count
   sp++;
   c->nodes_visited++; /* the root record */
   uint64_t pops = 0, t_before = c->tris_tested;
+  int deepest = 0;
   while (sp > 0) {
+    if (sp - 1 > deepest) deepest = sp - 1; /* entries waiting while the top one is followed */
     --sp;
     ++pops;
     int top = stack[sp];
@@ -245,6 +254,7 @@ static HitResult hit_bvh(const jade_scene* s, Ray ray, int src_object_idx, count
   }
   hist_add(0, pops);
   hist_add(1, c->tris_tested - t_before + 1);
+  __sync_fetch_and_add(&g_stack_hist[deepest < 63 ? deepest : 63], 1);
   return res;
 }
 
