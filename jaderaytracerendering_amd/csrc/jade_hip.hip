@@ -34,7 +34,9 @@ struct alignas(8) QueueCtl {
   uint32_t count;   // rays emitted by the last shade pass          } one 64-bit word: k_shade reserves its queue
   uint32_t active;  // records with rays in flight after that pass } and list space with ONE atomic per block
   uint32_t next;    // next unclaimed queue entry (trace)
+  uint32_t heavy;   // records k_shade_lean handed to k_shade this pass
   uint32_t fp_bad;  // jade_fp_selftest result (checked once)
+  uint32_t pad[3];
 };
 
 static __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t* total) {
@@ -122,20 +124,18 @@ __global__ __launch_bounds__(256) void k_arm(PathState P, uint32_t target_spp, u
 #endif
 #define JADE_SHADE_NW (JADE_SHADE_BLOCK / 64)
 #ifndef JADE_SHADE_WAVES
-#define JADE_SHADE_WAVES 4 /* 128 VGPRs, no spill: +3 % over 3 waves/SIMD */
+#define JADE_SHADE_WAVES 6 /* k_shade: 75 VGPRs, no spill (7 would spill 16 B).  +4 % over 5 when it runs alone, +-0 behind k_shade_lean */
 #endif
-__global__ __launch_bounds__(JADE_SHADE_BLOCK, JADE_SHADE_WAVES) void k_shade(DevScene S, PathState P, RenderConst R, const int32_t* tile_ids,
-                                               uint32_t target_spp, const uint32_t* active_in, uint32_t n_active,
-                                               uint32_t* active_out, uint32_t* queue, QueueCtl* qc, DevCounters* ctr) {
-  __shared__ uint32_t sh_rays[JADE_SHADE_NW], sh_act[JADE_SHADE_NW], sh_base[2];
-  __shared__ uint32_t sh_ctr[JADE_SHADE_NW][4];
-  const uint32_t t_idx = blockIdx.x * blockDim.x + threadIdx.x;
+// One record's shade pass (see the file header).  LEAN = the kernel that only knows camera rays,
+// the sky and pure mirrors: it hands every other record to the full kernel through `defer`
+// (either untouched, or parked at ST_VERTEX with its path state stored).  Same statements either
+// way: the lean paths are the shared helpers consume_mirror / begin_bounce_lean / bounce_mirror.
+template <bool LEAN>
+static __device__ __forceinline__ void shade_record(const DevScene& S, const PathState& P, const RenderConst& R, const int32_t* tile_ids,
+                                                    uint32_t target_spp, const int p, ShadeCtx& c, uint32_t& st_out, bool& defer) {
   const int npix = P.npix;
-  const int p = t_idx < n_active ? (int)active_in[t_idx] : npix;
-  ShadeCtx c;
-  c.n_emit_rays = 0;
-  c.c_primary = c.c_secondary = c.c_shaded = c.c_samples = 0;
   uint32_t st = ST_INVALID;
+  defer = false;
   // Prologue: everything most record-passes need, requested together so the pass is one
   // round trip deep instead of one per field (the kernel is latency-bound: PMC shows its
   // waves parked on s_waitcnt 74 % of the time).
@@ -155,6 +155,12 @@ __global__ __launch_bounds__(JADE_SHADE_BLOCK, JADE_SHADE_WAVES) void k_shade(De
     // sky, or -> mirror floor -> sky) touches ~90 B per pass, not the whole
     // ~230-B record; only records on a multi-bounce path carry thr/acc/le/....
     const bool on_path = st >= ST_DIFFUSE && st <= ST_REFRACT_EXIT;
+    if (LEAN && on_path && st != ST_MIRROR) {  // needs the full kernel: hand it over untouched
+      defer = true;
+      st_out = st;
+      return;
+    }
+    const bool has_ctx = on_path || st == ST_VERTEX;  // ST_VERTEX: handed over by the lean kernel this pass
     c.rng = rng0;
     c.depth = (word >> 8) & 255u;
     c.flags = word >> 16;
@@ -165,7 +171,7 @@ __global__ __launch_bounds__(JADE_SHADE_BLOCK, JADE_SHADE_WAVES) void k_shade(De
     c.obj = 0;
     c.src = jv(0, 0, 0);
     c.out = jv(0, 0, 0);
-    if (on_path) {
+    if (has_ctx) {
       c.thr = ld3(P.thr, npix, p);
       c.acc = ld3(P.acc, npix, p);
       c.le = ld3(P.le, npix, p);
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(JADE_SHADE_BLOCK, JADE_SHADE_WAVES) void k_shade(De
         st = ST_VERTEX;
       }
     } else if (on_path) {
-      int r = consume(S, px, c, &l_final);
+      int r = LEAN ? consume_mirror(S, px, c, &l_final) : consume(S, px, c, &l_final);
       if (r == CONSUME_VERTEX) {
         st = ST_VERTEX;
       } else if (r == CONSUME_EMITTED) {
@@ -224,7 +230,11 @@ __global__ __launch_bounds__(JADE_SHADE_BLOCK, JADE_SHADE_WAVES) void k_shade(De
         st = ST_IDLE;
       }
       if (st == ST_VERTEX) {
-        if (begin_bounce(S, px, c, &l_final)) {
+        if (LEAN && !lean_can_shade(&S.tris[c.obj])) {  // jade / diffuse / glass: the full kernel continues from here
+          defer = true;
+          break;
+        }
+        if (LEAN ? begin_bounce_lean(S, px, c, &l_final) : begin_bounce(S, px, c, &l_final)) {
           st = c.stage;
           break;
         }
@@ -265,7 +275,7 @@ __global__ __launch_bounds__(JADE_SHADE_BLOCK, JADE_SHADE_WAVES) void k_shade(De
     P.rng[p] = c.rng;
     P.done[p] = done;
     P.stage[p] = st | (c.depth << 8) | (c.flags << 16);
-    if (st >= ST_DIFFUSE && st <= ST_REFRACT_EXIT) {
+    if ((st >= ST_DIFFUSE && st <= ST_REFRACT_EXIT) || st == ST_VERTEX) {
       st3(P.thr, npix, p, c.thr);
       st3(P.acc, npix, p, c.acc);
       st3(P.le, npix, p, c.le);
@@ -274,43 +284,60 @@ __global__ __launch_bounds__(JADE_SHADE_BLOCK, JADE_SHADE_WAVES) void k_shade(De
       st3(P.out, npix, p, c.out);
     }
   }
+  st_out = st;
+}
 
-  // (c) queue the emitted rays and list this record for the next pass: wave
-  // scans, then ONE atomic per block and list (not per wave: see DevCounters)
+// Queue the emitted rays, list the record for the next pass and/or for the full kernel: wave scans,
+// then ONE atomic per block for queue + list (not per wave: see DevCounters).
+template <bool LEAN>
+static __device__ __forceinline__ void shade_tail(const PathState& P, int p, uint32_t st, const ShadeCtx& c, bool defer,
+                                                  uint32_t* active_out, uint32_t* heavy_out, uint32_t* queue, QueueCtl* qc,
+                                                  DevCounters* ctr) {
+  __shared__ uint32_t sh_rays[JADE_SHADE_NW], sh_act[JADE_SHADE_NW], sh_def[JADE_SHADE_NW], sh_base[3];
+  __shared__ uint32_t sh_ctr[JADE_SHADE_NW][4];
+  const int npix = P.npix;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   uint32_t total;
   const uint32_t off = wave_excl_scan((uint32_t)c.n_emit_rays, &total);
   const bool live = c.n_emit_rays > 0;
-  const unsigned long long am = __ballot(live);
-  const uint32_t aoff = (uint32_t)__popcll(am & ((1ull << lane) - 1ull));
+  const unsigned long long am = __ballot(live), dm = LEAN ? __ballot(defer) : 0ull;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const uint32_t aoff = (uint32_t)__popcll(am & below), doff = (uint32_t)__popcll(dm & below);
   if (lane == 0) {
     sh_rays[w] = total;
     sh_act[w] = (uint32_t)__popcll(am);
+    sh_def[w] = (uint32_t)__popcll(dm);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    uint32_t tr = 0, ta = 0;
+    uint32_t tr = 0, ta = 0, td = 0;
     for (int i = 0; i < JADE_SHADE_NW; ++i) {
       tr += sh_rays[i];
       ta += sh_act[i];
+      td += sh_def[i];
     }
     // count can never carry into active: a pass emits < 2^32 rays (nslots * npix < 2^32 is checked in jade_render_begin)
     const unsigned long long got =
         (tr | ta) ? atomicAdd(reinterpret_cast<unsigned long long*>(&qc->count), (unsigned long long)tr | ((unsigned long long)ta << 32)) : 0ull;
     sh_base[0] = (uint32_t)got;
     sh_base[1] = (uint32_t)(got >> 32);
+    sh_base[2] = (LEAN && td) ? atomicAdd(&qc->heavy, td) : 0u;
   }
   __syncthreads();
-  if (live) {
-    uint32_t wq = sh_base[0] + off, wa = sh_base[1] + aoff;
+  if (live || (LEAN && defer)) {
+    uint32_t wq = sh_base[0] + off, wa = sh_base[1] + aoff, wd = sh_base[2] + doff;
     for (int i = 0; i < w; ++i) {
       wq += sh_rays[i];
       wa += sh_act[i];
+      wd += sh_def[i];
     }
-    active_out[wa] = (uint32_t)p;
-    const int used = (st == ST_DIFFUSE || st == ST_BSSRDF) ? P.nslots : 1;
-    for (int k = 0; k < used; ++k)
-      if (P.hit[(size_t)k * npix + p] == -1) queue[wq++] = (uint32_t)k * (uint32_t)npix + (uint32_t)p;
+    if (LEAN && defer) heavy_out[wd] = (uint32_t)p;
+    if (live) {
+      if (active_out) active_out[wa] = (uint32_t)p;
+      const int used = (st == ST_DIFFUSE || st == ST_BSSRDF) ? P.nslots : 1;
+      for (int k = 0; k < used; ++k)
+        if (P.hit[(size_t)k * npix + p] == -1) queue[wq++] = (uint32_t)k * (uint32_t)npix + (uint32_t)p;
+    }
   }
   // work counters: per wave into LDS, then one set of atomics per block
   const uint32_t s0 = (uint32_t)wave_sum_u32(c.c_primary), s1 = (uint32_t)wave_sum_u32(c.c_secondary),
@@ -329,6 +356,41 @@ __global__ __launch_bounds__(JADE_SHADE_BLOCK, JADE_SHADE_WAVES) void k_shade(De
     unsigned long long* dst = threadIdx.x == 0 ? &cs->rays_primary : threadIdx.x == 1 ? &cs->rays_secondary : threadIdx.x == 2 ? &cs->shaded_hits : &cs->samples;
     if (t) atomicAdd(dst, t);
   }
+}
+
+// The full shade kernel: one thread per entry of `list` (the active list, or — after k_shade_lean —
+// the records that kernel handed over, whose count lives on the device: n_dev).  128 VGPRs, 4 waves/SIMD.
+__global__ __launch_bounds__(JADE_SHADE_BLOCK, JADE_SHADE_WAVES) void k_shade(DevScene S, PathState P, RenderConst R, const int32_t* tile_ids,
+                                               uint32_t target_spp, const uint32_t* list, uint32_t n_host, const uint32_t* n_dev,
+                                               uint32_t* active_out, uint32_t* queue, QueueCtl* qc, DevCounters* ctr) {
+  const uint32_t n = n_dev ? *n_dev : n_host;
+  if (blockIdx.x * blockDim.x >= n) return;  // block-uniform: the grid is sized for an upper bound of n_dev
+  const uint32_t t_idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int p = t_idx < n ? (int)list[t_idx] : P.npix;
+  ShadeCtx c;
+  c.n_emit_rays = 0;
+  c.c_primary = c.c_secondary = c.c_shaded = c.c_samples = 0;
+  uint32_t st;
+  bool defer;
+  shade_record<false>(S, P, R, tile_ids, target_spp, p, c, st, defer);
+  shade_tail<false>(P, p, st, c, false, active_out, nullptr, queue, qc, ctr);
+}
+
+// The lean shade kernel: camera rays, the sky and pure mirrors only — what most records of most
+// scenes do most of the time — in 56 VGPRs (8 waves/SIMD; the kernel is latency-bound).  It walks
+// ALL records in record order (no list: perfectly coalesced, and nothing to fragment) and hands
+// every record that needs anything else to k_shade through heavy_out / qc->heavy.
+__global__ __launch_bounds__(JADE_SHADE_BLOCK) void k_shade_lean(DevScene S, PathState P, RenderConst R, const int32_t* tile_ids,
+                                                                 uint32_t target_spp, uint32_t* heavy_out, uint32_t* queue,
+                                                                 QueueCtl* qc, DevCounters* ctr) {
+  const int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);  // >= npix: no record (shade_record checks)
+  ShadeCtx c;
+  c.n_emit_rays = 0;
+  c.c_primary = c.c_secondary = c.c_shaded = c.c_samples = 0;
+  uint32_t st;
+  bool defer;
+  shade_record<true>(S, P, R, tile_ids, target_spp, p, c, st, defer);
+  shade_tail<true>(P, p, st, c, defer, nullptr, heavy_out, queue, qc, ctr);
 }
 
 #ifndef JADE_TRACE_WAVES
@@ -824,20 +886,54 @@ static int run_passes(jade_scene* s, uint32_t target_spp, double* ms_out, double
   uint32_t n_active = host_ctl[1];
   int cur = 0, pass_no = 0;
   const bool log_passes = getenv("JADE_LOG_PASSES") != nullptr;
-  hipEvent_t sa, sb;
-  float shade_ms = 0;
+  // While at least a quarter of the records are active, a pass is k_shade_lean over all records
+  // (record order, no list) followed by k_shade over what it handed over; below that, k_shade alone
+  // over the active list, which k_arm rebuilds once at the switch.  JADE_SHADE_SPLIT=0: always the list.
+  const bool split_ok = !(getenv("JADE_SHADE_SPLIT") && atoi(getenv("JADE_SHADE_SPLIT")) == 0);
+  bool have_list = true;  // b_active[cur] lists the active records
+  hipEvent_t sa, sb, sm;
+  float shade_ms = 0, lean_ms = 0;
   HIP_TRY(hipEventCreate(&sa));
   HIP_TRY(hipEventCreate(&sb));
+  HIP_TRY(hipEventCreate(&sm));
   while (n_active) {
-    HIP_TRY(hipMemsetAsync(qc, 0, 12, s->stream));  // count, next, active
+    const bool lean_mode = split_ok && (uint64_t)n_active * 4 >= (uint64_t)npix;
+    if (!lean_mode && !have_list) {
+      cur = 0;
+      HIP_TRY(hipMemsetAsync(qc, 0, 16, s->stream));
+      hipLaunchKernelGGL(k_arm, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s->stream, s->ps, target_spp,
+                         s->b_active[0].as<uint32_t>(), qc);
+      have_list = true;
+    }
+    HIP_TRY(hipMemsetAsync(qc, 0, 16, s->stream));  // count, active, next, heavy
     if (log_passes) HIP_TRY(hipEventRecord(sa, s->stream));
-    hipLaunchKernelGGL(k_shade, dim3((n_active + JADE_SHADE_BLOCK - 1) / JADE_SHADE_BLOCK), dim3(JADE_SHADE_BLOCK), 0, s->stream, s->dev, s->ps, s->rc,
-                       s->b_tiles.as<int32_t>(), target_spp, s->b_active[cur].as<uint32_t>(), n_active,
-                       s->b_active[cur ^ 1].as<uint32_t>(), s->b_queue.as<uint32_t>(), qc, s->b_ctr.as<DevCounters>());
+    const unsigned nb = (n_active + JADE_SHADE_BLOCK - 1) / JADE_SHADE_BLOCK;
+    if (lean_mode) {
+      // b_active[1] carries the hand-over list; no active list is kept in this mode
+      hipLaunchKernelGGL(k_shade_lean, dim3((unsigned)((npix + JADE_SHADE_BLOCK - 1) / JADE_SHADE_BLOCK)), dim3(JADE_SHADE_BLOCK), 0,
+                         s->stream, s->dev, s->ps, s->rc, s->b_tiles.as<int32_t>(), target_spp, s->b_active[1].as<uint32_t>(),
+                         s->b_queue.as<uint32_t>(), qc, s->b_ctr.as<DevCounters>());
+      if (log_passes) HIP_TRY(hipEventRecord(sm, s->stream));
+      // only a record that was active can be handed over: n_active bounds the grid, the count stays on the device
+      hipLaunchKernelGGL(k_shade, dim3(nb), dim3(JADE_SHADE_BLOCK), 0, s->stream, s->dev, s->ps, s->rc, s->b_tiles.as<int32_t>(),
+                         target_spp, s->b_active[1].as<uint32_t>(), 0u, &qc->heavy, (uint32_t*)nullptr, s->b_queue.as<uint32_t>(), qc,
+                         s->b_ctr.as<DevCounters>());
+      have_list = false;
+    } else {
+      if (log_passes) HIP_TRY(hipEventRecord(sm, s->stream));
+      hipLaunchKernelGGL(k_shade, dim3(nb), dim3(JADE_SHADE_BLOCK), 0, s->stream, s->dev, s->ps, s->rc, s->b_tiles.as<int32_t>(),
+                         target_spp, s->b_active[cur].as<uint32_t>(), n_active, (const uint32_t*)nullptr,
+                         s->b_active[cur ^ 1].as<uint32_t>(), s->b_queue.as<uint32_t>(), qc, s->b_ctr.as<DevCounters>());
+      cur ^= 1;
+    }
+    HIP_TRY(hipGetLastError());
     if (log_passes) HIP_TRY(hipEventRecord(sb, s->stream));
     HIP_TRY(hipMemcpyAsync(host_ctl, qc, 12, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
-    if (log_passes) HIP_TRY(hipEventElapsedTime(&shade_ms, sa, sb));
+    if (log_passes) {
+      HIP_TRY(hipEventElapsedTime(&shade_ms, sa, sb));
+      HIP_TRY(hipEventElapsedTime(&lean_ms, sa, sm));
+    }
     if (trace_pending) {
       float t = 0;
       HIP_TRY(hipEventElapsedTime(&t, ta, tb));
@@ -846,7 +942,6 @@ static int run_passes(jade_scene* s, uint32_t target_spp, double* ms_out, double
       trace_pending = false;
     }
     n_active = host_ctl[1];
-    cur ^= 1;
     if (host_ctl[0] == 0) break;
     HIP_TRY(hipEventRecord(ta, s->stream));
     hipLaunchKernelGGL(k_trace, dim3((unsigned)s->trace_blocks), dim3(JADE_TRACE_BLOCK), 0, s->stream, s->dev, s->ps,
@@ -859,8 +954,8 @@ static int run_passes(jade_scene* s, uint32_t target_spp, double* ms_out, double
       HIP_TRY(hipEventSynchronize(tb));
       float t = 0;
       HIP_TRY(hipEventElapsedTime(&t, ta, tb));
-      fprintf(stderr, "[jade] pass %4d active %9u rays %9u shade %7.3f ms trace %8.3f ms (%7.1f Mray/s)\n", pass_no, n_active,
-              host_ctl[0], shade_ms, t, host_ctl[0] / (t * 1e3));
+      fprintf(stderr, "[jade] pass %4d active %9u rays %9u shade %7.3f ms (lean %6.3f) trace %8.3f ms (%7.1f Mray/s)\n", pass_no,
+              n_active, host_ctl[0], shade_ms, lean_ms, t, host_ctl[0] / (t * 1e3));
     }
     ++pass_no;
   }

@@ -148,6 +148,53 @@ static __device__ __forceinline__ bool path_push(ShadeCtx& c, jvec3 dirv, jvec3 
   return c.depth >= JADE_STACK_CAPACITY;
 }
 
+// The mirror branch of the bounce loop (PathTrace.cu:1365-1405): RR, then the reflected ray.
+// Shared by the full shading kernel and the lean one (k_shade<true>).
+static __device__ __forceinline__ bool bounce_mirror(const Px& px, ShadeCtx& c, const jade_triangle* ot, jvec3 obj_emissive, jvec3 n,
+                                                     jvec3* l_final) {
+  const float RR_F = (float)JADE_RR_RATE_D;
+  const int pix = px.p, npix = px.P.npix;
+  jvec3 obj_hit_fr = jv_scale(V3(ot->brdf), (float)(1.0 / JADE_PI_D));
+  int k = ot->refract_mode != JADE_NO_REFRACT ? 2 : 1;
+  if (obj_emissive.x > 1.5e-4f || obj_emissive.y > 1.5e-4f || obj_emissive.x > 1.5e-4f) {
+    *l_final = jv_scale(jv_mul(obj_emissive, obj_hit_fr), (float)k);
+    return false;
+  }
+  float rr_result = jade_rand(&c.rng);
+  if (!(rr_result < RR_F)) return false;
+  jvec3 refl = jv_sub(jv_scale(n, 2 * jv_dot(c.out, n)), c.out);
+  st3(px.P.org, npix, pix, c.src);
+  px.P.skip[pix] = c.obj;
+  px.set_dir(0, refl);
+  px.set_hit(0, -1);
+  c.n_emit_rays++;
+  c.stage = ST_MIRROR;
+  c.flags = 0;
+  return true;
+}
+
+// What the lean kernel may shade at a vertex: an emitter (the loop's first test ends the path) or a
+// pure mirror (no refraction branch, not diffuse).  Everything else needs the full kernel.
+static __device__ __forceinline__ bool lean_can_shade(const jade_triangle* ot) {
+  if (ot->emissive[0] > 1.4e-5f || ot->emissive[1] > 1.4e-5f || ot->emissive[2] > 1.4e-5f) return true;
+  return ot->refract_mode == JADE_NO_REFRACT && ot->reflex_mode != JADE_DIFFUSE;
+}
+
+// begin_bounce restricted to those two cases: the same statements in the same order
+// (emissive test :916-920, the select draw :924, then the mirror branch).
+static __device__ bool begin_bounce_lean(const DevScene& S, const Px& px, ShadeCtx& c, jvec3* l_final) {
+  const jade_triangle* ot = &S.tris[c.obj];
+  c.c_shaded += 1;
+  jvec3 obj_emissive = V3(ot->emissive);
+  if (obj_emissive.x > 1.4e-5f || obj_emissive.y > 1.4e-5f || obj_emissive.z > 1.4e-5f) {
+    *l_final = obj_emissive;
+    return false;
+  }
+  *l_final = jv(0, 0, 0);
+  (void)jade_rand(&c.rng);  // select_reflex_refract: drawn for every material, decides nothing for a pure mirror
+  return bounce_mirror(px, c, ot, obj_emissive, V3(ot->norm), l_final);
+}
+
 // Sample the bounce at the current vertex and emit its rays.  Returns false
 // if the path ended at this vertex (l_final holds the last l_dir).
 static __device__ bool begin_bounce(const DevScene& S, const Px& px, ShadeCtx& c, jvec3* l_final) {
@@ -276,25 +323,7 @@ static __device__ bool begin_bounce(const DevScene& S, const Px& px, ShadeCtx& c
     goto diffuse_like;
   }
   // ---- mirror, PathTrace.cu:1365-1405 ----
-  {
-    jvec3 obj_hit_fr = jv_scale(V3(ot->brdf), (float)(1.0 / JADE_PI_D));
-    int k = ot->refract_mode != JADE_NO_REFRACT ? 2 : 1;
-    if (obj_emissive.x > 1.5e-4f || obj_emissive.y > 1.5e-4f || obj_emissive.x > 1.5e-4f) {
-      *l_final = jv_scale(jv_mul(obj_emissive, obj_hit_fr), (float)k);
-      return false;
-    }
-    float rr_result = jade_rand(&c.rng);
-    if (!(rr_result < RR_F)) return false;
-    jvec3 refl = jv_sub(jv_scale(n, 2 * jv_dot(c.out, n)), c.out);
-    st3(px.P.org, npix, pix, c.src);
-    px.P.skip[pix] = c.obj;
-    px.set_dir(0, refl);
-    px.set_hit(0, -1);
-    c.n_emit_rays++;
-    c.stage = ST_MIRROR;
-    c.flags = 0;
-    return true;
-  }
+  return bounce_mirror(px, c, ot, obj_emissive, n, l_final);
 
 diffuse_like:
   // ---- diffuse (:1266-1364) and SSS-diffuse (:931-1028): same ray set ----
@@ -343,6 +372,25 @@ diffuse_like:
 
 // Outcome of folding the pending rays' results into the path.
 enum { CONSUME_VERTEX = 0, CONSUME_END = 1, CONSUME_ZERO = 2, CONSUME_EMITTED = 3 };
+
+// Result of the mirror ray (PathTrace.cu:1383-1398).  Shared by both shading kernels.
+static __device__ __forceinline__ int consume_mirror(const DevScene& S, const Px& px, ShadeCtx& c, jvec3* l_final) {
+  const jade_triangle* ot = &S.tris[c.obj];
+  const int k = ot->refract_mode != JADE_NO_REFRACT ? 2 : 1;
+  const jvec3 obj_hit_fr = jv_scale(V3(ot->brdf), (float)(1.0 / JADE_PI_D));
+  float kk = (float)(k / (JADE_RR_RATE_D / JADE_PI_D));
+  jvec3 refl = px.dir(0);
+  int nh = px.hit(0);
+  if (nh >= 0) {
+    c.out = jv_neg(refl);
+    c.src = px.hpt(0);
+    c.obj = nh;
+    *l_final = jv(0, 0, 0);
+    return path_push(c, jv(0, 0, 0), jv_scale(obj_hit_fr, kk)) ? CONSUME_END : CONSUME_VERTEX;
+  }
+  *l_final = jv_scale(jv_mul(sample_hdr(S, refl), obj_hit_fr), kk);
+  return CONSUME_END;
+}
 
 // Fold the results of the rays issued last pass.  CONSUME_VERTEX: the path
 // moved to a new vertex (c.obj/src/out updated); CONSUME_END: it ended with
@@ -453,20 +501,7 @@ static __device__ int consume(const DevScene& S, const Px& px, ShadeCtx& c, jvec
     return CONSUME_END;
   }
 
-  if (c.stage == ST_MIRROR) {
-    float kk = (float)(k / (JADE_RR_RATE_D / JADE_PI_D));
-    jvec3 refl = px.dir(0);
-    int nh = px.hit(0);
-    if (nh >= 0) {
-      c.out = jv_neg(refl);
-      c.src = px.hpt(0);
-      c.obj = nh;
-      *l_final = jv(0, 0, 0);
-      return path_push(c, jv(0, 0, 0), jv_scale(obj_hit_fr, kk)) ? CONSUME_END : CONSUME_VERTEX;
-    }
-    *l_final = jv_scale(jv_mul(sample_hdr(S, refl), obj_hit_fr), kk);
-    return CONSUME_END;
-  }
+  if (c.stage == ST_MIRROR) return consume_mirror(S, px, c, l_final);
 
   if (c.stage == ST_REFRACT_LOOP) {
     // one iteration of the for loop at PathTrace.cu:1201-1234

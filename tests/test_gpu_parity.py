@@ -146,6 +146,26 @@ def test_result_independent_of_paths_in_flight(hip, monkeypatch):
             assert counters(st) == ref[2]
 
 
+def test_result_independent_of_shade_schedule(hip, monkeypatch):
+    """A pass is either k_shade_lean over all records + k_shade over what it hands over, or k_shade
+    alone over the active list (the backend switches on the share of active records):
+    JADE_SHADE_SPLIT=0 forces the second form, and every bit of the result must be the same."""
+    for name, spp in (("tinyjade", 24), ("C1", 6)):
+        hs, cfg = config_scene(name)
+        p = B.params_from_config(cfg, spp=spp)
+        p.width, p.height = 40, 36
+        ref = None
+        for split in ("1", "0"):
+            monkeypatch.setenv("JADE_SHADE_SPLIT", split)
+            with hip.scene(hs) as sc:
+                rgb, bgr, st = sc.render(p)
+            if ref is None:
+                ref = (rgb, bgr, counters(st))
+            else:
+                assert np.array_equal(rgb.view(np.uint32), ref[0].view(np.uint32)) and np.array_equal(bgr, ref[1])
+                assert counters(st) == ref[2]
+
+
 def test_many_samples_per_lane_match_oracle(oracle, hip):
     """spp > JADE_SAMPLE_LANES: several samples per lane, summed in lane order by both backends."""
     hs, cfg = config_scene("tiny")
