@@ -27,6 +27,7 @@
 
 #define JADE_REF_LEAF 0x80000000u
 #define JADE_REF_NONE 0x7fffffffu
+#define JADE_MAX_TRIS ((1 << 27) / 3) /* leaf refs carry 48 * first_triangle in bits 4-30 (jade_trace.h) */
 #define JADE_MAX_LEAF 15
 #define JADE_INF_F 2147483647.0f /* #define INF, PathTrace.cu:23 */
 
@@ -134,7 +135,9 @@ struct DevCounters {
 #ifndef JADE_TRACE_CHUNK
 #define JADE_TRACE_CHUNK 512 /* most rays a wave claims per queue atomic */
 #endif
-#define JADE_REFILL_MIN 16    /* idle lanes in a wave that trigger a refill */
+#ifndef JADE_REFILL_MIN
+#define JADE_REFILL_MIN 16 /* idle lanes in a wave that trigger write-back + refill */
+#endif
 
 static __device__ __forceinline__ jvec3 ld3(const float* a, int npix, int p) {
   return jv(a[p], a[npix + p], a[2 * npix + p]);

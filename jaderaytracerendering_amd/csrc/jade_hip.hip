@@ -393,6 +393,15 @@ __global__ __launch_bounds__(JADE_SHADE_BLOCK) void k_shade_lean(DevScene S, Pat
   shade_tail<true>(P, p, st, c, defer, nullptr, heavy_out, queue, qc, ctr);
 }
 
+#ifndef JADE_PHASED
+#define JADE_PHASED 0
+#endif
+#ifndef JADE_COST_NODE
+#define JADE_COST_NODE 150 /* instructions issued for a node visit ... */
+#endif
+#ifndef JADE_COST_TRI
+#define JADE_COST_TRI 180  /* ... and for a triangle test (JADE_PHASED) */
+#endif
 #ifndef JADE_TRACE_WAVES
 #define JADE_TRACE_WAVES 1
 #endif
@@ -413,60 +422,81 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
   uint32_t lbase = 0, lend = 0;
   bool queue_empty = false;
   bool active = false;
+  bool wb = false;    // this lane's ray has finished and its result is still in the LDS column
   uint32_t my_e = 0;  // this lane's queue entry: slot * npix + record
   RayState r;
   for (;;) {
-    // ---- refill idle lanes once enough of them are idle (or all are)
+    // ---- once enough lanes are idle (or all are): write their results back and refill them.
+    // Both are done for >= JADE_REFILL_MIN lanes at a time, not whenever a single ray ends:
+    // the kernel is VALU-bound and a block that runs for one lane costs as much as for 64.
     const unsigned long long idle = __ballot(!active);
     const int n_idle = __popcll(idle);
-    if (n_idle >= JADE_REFILL_MIN && !queue_empty) {
-      if (lbase >= lend) {
-        uint32_t nb = 0;
-        if (lane == 0) nb = atomicAdd(&qc->next, chunk);
-        nb = __shfl(nb, 0, 64);
-        if (nb >= n) {
-          queue_empty = true;
-          lbase = lend = n;
-        } else {
-          lbase = nb;
-          lend = nb + chunk < n ? nb + chunk : n;
+    if (n_idle >= JADE_REFILL_MIN) {
+      if (wb) {
+        const int32_t best = ray_best_index(stk);
+        P.hit[my_e] = best;
+        if (best >= 0) {  // the hit point of a miss is never read
+          const jvec3 hp = ray_hit_point(stk);
+          float* hb = P.hpt + my_e;
+          hb[0] = hp.x;
+          hb[plane] = hp.y;
+          hb[2 * plane] = hp.z;
         }
+        wb = false;
       }
-      const uint32_t avail = lend - lbase;
-      const uint32_t take = (uint32_t)n_idle < avail ? (uint32_t)n_idle : avail;
-      const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-      if (!active && rank < take) {
-        my_e = queue[lbase + rank];
-        const uint32_t k = my_e / (uint32_t)npix, p = my_e - k * (uint32_t)npix;
-        const jvec3 o = ld3(P.org, npix, p);
-        const float* db = P.dir + my_e;
-        const jvec3 d = jv(db[0], db[plane], db[2 * plane]);
-        ray_begin(r, stk, S, o, d, P.skip[p]);
-        active = true;
+      if (!queue_empty) {
+        if (lbase >= lend) {
+          uint32_t nb = 0;
+          if (lane == 0) nb = atomicAdd(&qc->next, chunk);
+          nb = __shfl(nb, 0, 64);
+          if (nb >= n) {
+            queue_empty = true;
+            lbase = lend = n;
+          } else {
+            lbase = nb;
+            lend = nb + chunk < n ? nb + chunk : n;
+          }
+        }
+        const uint32_t avail = lend - lbase;
+        const uint32_t take = (uint32_t)n_idle < avail ? (uint32_t)n_idle : avail;
+        const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+        if (!active && rank < take) {
+          my_e = queue[lbase + rank];
+          const uint32_t k = my_e / (uint32_t)npix, p = my_e - k * (uint32_t)npix;
+          const jvec3 o = ld3(P.org, npix, p);
+          const float* db = P.dir + my_e;
+          const jvec3 d = jv(db[0], db[plane], db[2 * plane]);
+          ray_begin(r, stk, S, o, d, P.skip[p]);
+          active = true;
+        }
+        V += take;  // the root record of every ray started
+        lbase += take;
       }
-      V += take;  // the root record of every ray started
-      lbase += take;
     }
-    if (n_idle == 64 && queue_empty) break;  // nothing in flight, nothing left to claim
+    if (n_idle == 64 && queue_empty) break;  // nothing in flight, nothing left to claim (results are written: 64 >= REFILL_MIN)
     // ---- one traversal unit per lane
     bool fin = false, c1 = false, c2 = false, tested = false;
+#if JADE_PHASED
+    {  // one kind of unit per iteration: whichever advances more lanes per instruction issued
+      const bool wt = active && ray_in_leaf(r), wn = active && !ray_in_leaf(r);
+      const int nt = __popcll(__ballot(wt)), nn = __popcll(__ballot(wn));
+      if (JADE_COST_TRI * nn >= JADE_COST_NODE * nt) {
+        if (wn) fin = !ray_step_node(r, S, stk, &c1, &c2);
+      } else {
+        if (wt) fin = !ray_step_tri(r, S, stk, &tested);
+      }
+    }
+#else
     if (active) {
       if (ray_in_leaf(r)) fin = !ray_step_tri(r, S, stk, &tested);
       else fin = !ray_step_node(r, S, stk, &c1, &c2);
     }
+#endif
     V += (uint32_t)__popcll(__ballot(c1)) + (uint32_t)__popcll(__ballot(c2));
     T += (uint32_t)__popcll(__ballot(tested));
     if (fin) {
-      const int32_t best = ray_best_index(stk);
-      P.hit[my_e] = best;
-      if (best >= 0) {  // the hit point of a miss is never read
-        const jvec3 hp = ray_hit_point(stk);
-        float* hb = P.hpt + my_e;
-        hb[0] = hp.x;
-        hb[plane] = hp.y;
-        hb[2 * plane] = hp.z;
-      }
       active = false;
+      wb = true;
     }
   }
   if (lane == 0) {
@@ -609,7 +639,7 @@ static int validate_desc(const jade_scene_desc* d, int* depth_out) {
   if (d->abi_version != JADE_ABI_VERSION) return fail(JADE_ERR_INVALID, "abi_version mismatch");
   if (d->n_triangles <= 0 || d->n_nodes < 2 || !d->triangles || !d->nodes)
     return fail(JADE_ERR_INVALID, "scene needs triangles and a BVH (dummy node 0 + root 1)");
-  if (d->n_triangles >= (1 << 27)) return fail(JADE_ERR_UNSUPPORTED, "more than 2^27 triangles");
+  if (d->n_triangles >= JADE_MAX_TRIS) return fail(JADE_ERR_UNSUPPORTED, "too many triangles for the 27-bit leaf cursor (44.7 M)");
   if (d->n_emit < 0 || (d->n_emit > 0 && !d->emit_indices)) return fail(JADE_ERR_INVALID, "bad emitter list");
   if (!d->index_mapping || !d->prefix_area || d->n_objects <= 0 || !d->obj_segs)
     return fail(JADE_ERR_INVALID, "missing mapping / prefix areas / object segments");
@@ -668,7 +698,7 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
   auto ref_of = [&](int child) -> uint32_t {
     if (child <= 0) return JADE_REF_NONE;
     const jade_bvh_node& c = d->nodes[child];
-    if (c.n > 0) return JADE_REF_LEAF | ((uint32_t)c.index << 4) | (uint32_t)c.n;
+    if (c.n > 0) return JADE_REF_LEAF | ((uint32_t)c.index * 3u << 4) | (uint32_t)c.n;  // bits 4-30: byte offset of the first vertex record
     return (uint32_t)compact[child];
   };
   std::vector<float4> nodes((size_t)4 * std::max(n_internal, 1));

@@ -78,8 +78,17 @@ static __device__ __forceinline__ float slab(jvec3 o, jvec3 inv, float ax, float
     t1 = jade_fminf(tmaxx, jade_fminf(tmaxy, tmaxz));
     t0 = jade_fmaxf(tminx, jade_fmaxf(tminy, tminz));
   } else {
-    t1 = __builtin_fminf(__builtin_fmaxf(fx, nx), __builtin_fminf(__builtin_fmaxf(fy, ny), __builtin_fmaxf(fz, nz)));
-    t0 = __builtin_fmaxf(__builtin_fminf(fx, nx), __builtin_fmaxf(__builtin_fminf(fy, ny), __builtin_fminf(fz, nz)));
+    // no NaN can occur here, so plain v_max/v_min ARE the ternaries; spelled as instructions
+    // because the builtins make the compiler quiet each operand first (six extra v_max x,x,x)
+    float hx, hy, hz, lx, ly, lz;
+    asm("v_max_f32_e32 %0, %1, %2" : "=v"(hx) : "v"(fx), "v"(nx));
+    asm("v_max_f32_e32 %0, %1, %2" : "=v"(hy) : "v"(fy), "v"(ny));
+    asm("v_max_f32_e32 %0, %1, %2" : "=v"(hz) : "v"(fz), "v"(nz));
+    asm("v_min_f32_e32 %0, %1, %2" : "=v"(lx) : "v"(fx), "v"(nx));
+    asm("v_min_f32_e32 %0, %1, %2" : "=v"(ly) : "v"(fy), "v"(ny));
+    asm("v_min_f32_e32 %0, %1, %2" : "=v"(lz) : "v"(fz), "v"(nz));
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(t1) : "v"(hx), "v"(hy), "v"(hz));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t0) : "v"(lx), "v"(ly), "v"(lz));
   }
   return (t1 >= t0) ? ((t0 > 0.0f) ? t0 : t1) : -1.0f;
 }
@@ -122,13 +131,15 @@ static __device__ __forceinline__ bool finite_f(float x) { return (jade_f2u(x) &
 // to what fits 64 VGPRs (8 waves).  In registers: o, normalize(d), the skip index, the
 // cursor and the stack pointer.  In the lane's LDS column: 1/d (read by node visits only) and
 // the best hit so far (touched only when a triangle is actually hit).  The leaf cursor IS the
-// leaf reference: LEAF | first << 4 | count, advanced by +15 per triangle (first + 1, count - 1).
+// leaf reference: LEAF | 3 * first << 4 | count.  Bits 4-30 are the byte offset of the next
+// triangle's 48-B vertex record, so a step needs one AND to address it and +47 to advance
+// (offset + 48, count - 1); triangles are identified by that offset until the ray ends.
 struct V3ld {
   float x, y, z;
 };
 struct RayState {
   jvec3 o, dn;
-  uint32_t skipx;  // bit 31: a component of o or 1/d is not finite (NaN-faithful slab needed); bits 0-30: source triangle, 0x7fffffff = none
+  uint32_t skipx;  // bit 31: a component of o or 1/d is not finite (NaN-faithful slab needed); bits 0-30: 48 * source triangle, 0x7fffffff = none
   uint32_t cur;    // internal-node ref, or leaf cursor
   int sp;
 };
@@ -138,7 +149,7 @@ static __device__ __forceinline__ void ray_begin(RayState& r, const LdsStack& st
   const jvec3 inv = jv(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
   r.dn = jv_normalize(d);
   const bool exact = !(finite_f(inv.x) && finite_f(inv.y) && finite_f(inv.z)) || !finite_f(o.x) || !finite_f(o.y) || !finite_f(o.z);
-  r.skipx = (skip < 0 ? 0x7fffffffu : (uint32_t)skip) | (exact ? 0x80000000u : 0u);
+  r.skipx = (skip < 0 ? 0x7fffffffu : (uint32_t)skip * 48u) | (exact ? 0x80000000u : 0u);
   r.sp = 0;
   r.cur = S.root_ref;
   lds_putf(stk, LW_INVX, inv.x);
@@ -164,26 +175,26 @@ static __device__ __forceinline__ bool ray_pop(RayState& r, const LdsStack& stk)
 #define JADE_ABLATE_SLAB 0
 #endif
 
-static __device__ __forceinline__ int32_t ray_best_index(const LdsStack& stk) { return (int32_t)lds_get(stk, LW_BEST_INDEX); }
+static __device__ __forceinline__ int32_t ray_best_index(const LdsStack& stk) {
+  const uint32_t off = lds_get(stk, LW_BEST_INDEX);  // byte offset of the vertex record, or ~0
+  return off == 0xffffffffu ? -1 : (int32_t)(off / 48u);
+}
 static __device__ __forceinline__ jvec3 ray_hit_point(const LdsStack& stk) {
   return jv(lds_getf(stk, LW_PX), lds_getf(stk, LW_PY), lds_getf(stk, LW_PZ));
 }
 
 static __device__ __forceinline__ bool ray_in_leaf(const RayState& r) { return (r.cur & JADE_REF_LEAF) != 0; }
 
-// One triangle of the current leaf (hitArray, PathTrace.cu:776-792), in index order.
+// The next triangle of the current leaf (hitArray, PathTrace.cu:776-792), in index order.
 // *tested: this lane ran an intersection test (the skipped source triangle does not count).
 static __device__ __forceinline__ bool ray_step_tri(RayState& r, const DevScene& S, const LdsStack& stk, bool* tested) {
   if (r.cur & 15u) {
-    const uint32_t i = (r.cur & 0x7fffffffu) >> 4;
-    // 32-bit byte offsets from a scalar base (n_tris < 2^27: 48 B * i fits): saddr + voffset loads
-    // (three 12-B loads: the pad word of each vertex is never brought into a register)
-    const char* t0 = reinterpret_cast<const char*>(S.tverts) + i * 48u;
+    const uint32_t off = r.cur & 0x7ffffff0u;
+    // saddr + 32-bit voffset loads; three 12-B loads: the pad word of each vertex is never brought into a register
+    const char* t0 = reinterpret_cast<const char*>(S.tverts) + off;
     const V3ld a0 = *reinterpret_cast<const V3ld*>(t0), b0 = *reinterpret_cast<const V3ld*>(t0 + 16),
                c0 = *reinterpret_cast<const V3ld*>(t0 + 32);
-    r.cur += 15u;  // first + 1, count - 1
-    float dist;
-    jvec3 P;
+    r.cur += 47u;  // next record, count - 1
 #if JADE_ABLATE_TRI
     {
       float d2; jvec3 P2;
@@ -192,12 +203,14 @@ static __device__ __forceinline__ bool ray_step_tri(RayState& r, const DevScene&
       asm volatile("" ::"v"(h2 ? d2 + P2.x : 0.0f));
     }
 #endif
-    if (i != (r.skipx & 0x7fffffffu)) {
+    if (off != (r.skipx & 0x7fffffffu)) {
       *tested = true;
+      float dist;
+      jvec3 P;
       if (tri_test(jv(a0.x, a0.y, a0.z), jv(b0.x, b0.y, b0.z), jv(c0.x, c0.y, c0.z), r.o, r.dn, &dist, &P) &&
           dist < lds_getf(stk, LW_BEST_DIST)) {
         lds_putf(stk, LW_BEST_DIST, dist);
-        lds_put(stk, LW_BEST_INDEX, i);
+        lds_put(stk, LW_BEST_INDEX, off);
         lds_putf(stk, LW_PX, P.x);
         lds_putf(stk, LW_PY, P.y);
         lds_putf(stk, LW_PZ, P.z);
@@ -231,22 +244,15 @@ static __device__ __forceinline__ bool ray_step_node(RayState& r, const DevScene
     *c2 = true;
     d2 = slab(r.o, inv, b.z, b.w, c.x, c.y, c.z, c.w, exact);
   }
-  if (d1 > 0 && d2 > 0) {
-    if (d1 < d2) {
-      stack_push(stk, r.sp++, rf.y);
-      r.cur = rf.x;
-    } else {
-      stack_push(stk, r.sp++, rf.x);
-      r.cur = rf.y;
-    }
+  const bool in1 = d1 > 0, in2 = d2 > 0;
+  if (in1 && in2) {  // near child first (d1 < d2, PathTrace.cu:835-848): follow it, push the far one
+    const bool first = d1 < d2;
+    stack_push(stk, r.sp++, first ? rf.y : rf.x);
+    r.cur = first ? rf.x : rf.y;
     return true;
   }
-  if (d1 > 0) {
-    r.cur = rf.x;
-    return true;
-  }
-  if (d2 > 0) {
-    r.cur = rf.y;
+  if (in1 || in2) {
+    r.cur = in1 ? rf.x : rf.y;
     return true;
   }
   return ray_pop(r, stk);
