@@ -32,10 +32,14 @@
 #define JADE_INF_F 2147483647.0f /* #define INF, PathTrace.cu:23 */
 
 #ifndef JADE_LDS_STACK
-#define JADE_LDS_STACK 12 /* traversal stack entries kept in LDS per lane; deeper ones spill to global.  The deepest \
-                             stack of any ray is 12 on C3 and C5 (tools/ray_histogram.py): 99.97 % need <= 10 */
+#define JADE_LDS_STACK 8 /* traversal stack entries kept in LDS per lane; deeper ones spill to global.  The deepest \
+                            stack of any ray is 12 on C3 and C5 (tools/ray_histogram.py), 99.6 % need <= 8 */
 #endif
-#define JADE_LDS_STATE 8  /* ray-state words kept in the same LDS column (jade_trace.h): 20 words * 256 lanes = 20 KB/block, 8 blocks/CU */
+#ifndef JADE_LDS_FIFO
+#define JADE_LDS_FIFO 4
+#endif
+/* leaf cursors waiting for their triangle tests, same LDS column (power of two) */
+#define JADE_LDS_STATE 8  /* ray-state words, same column (jade_trace.h): 20 words * 256 lanes = 20 KB/block, 8 blocks/CU */
 #define JADE_TRACE_BLOCK 256
 #define JADE_RECORD_BUDGET (72ll << 20) /* path records kept in flight per GPU (~250 B each) */
 
@@ -136,7 +140,7 @@ struct DevCounters {
 #define JADE_TRACE_CHUNK 512 /* most rays a wave claims per queue atomic */
 #endif
 #ifndef JADE_REFILL_MIN
-#define JADE_REFILL_MIN 16 /* idle lanes in a wave that trigger write-back + refill */
+#define JADE_REFILL_MIN 32 /* idle lanes in a wave that trigger write-back + refill (8: 343, 16: 331, 32: 313, 48: 316 ms of k_trace per 256-spp step) */
 #endif
 
 static __device__ __forceinline__ jvec3 ld3(const float* a, int npix, int p) {

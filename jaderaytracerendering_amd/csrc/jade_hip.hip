@@ -393,21 +393,21 @@ __global__ __launch_bounds__(JADE_SHADE_BLOCK) void k_shade_lean(DevScene S, Pat
   shade_tail<true>(P, p, st, c, defer, nullptr, heavy_out, queue, qc, ctr);
 }
 
-#ifndef JADE_PHASED
-#define JADE_PHASED 0
+#ifndef JADE_STEPS_PER_PICK
+#define JADE_STEPS_PER_PICK 3 /* units of the picked kind per wave iteration (1: 313, 2: 306, 3: 303, 4: 301 ms with REFILL_MIN 32) */
 #endif
 #ifndef JADE_COST_NODE
-#define JADE_COST_NODE 150 /* instructions issued for a node visit ... */
+#define JADE_COST_NODE 100 /* instructions issued by a node-walk iteration ... */
 #endif
 #ifndef JADE_COST_TRI
-#define JADE_COST_TRI 180  /* ... and for a triangle test (JADE_PHASED) */
+#define JADE_COST_TRI 120  /* ... and by a triangle-test iteration (k_trace picks the kind per wave iteration) */
 #endif
 #ifndef JADE_TRACE_WAVES
 #define JADE_TRACE_WAVES 1
 #endif
 __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(DevScene S, PathState P, const uint32_t* queue, QueueCtl* qc,
                                                            uint32_t* spill, DevCounters* ctr, uint32_t chunk) {
-  __shared__ uint32_t lds_cols[(JADE_LDS_STACK + JADE_LDS_STATE) * JADE_TRACE_BLOCK];
+  __shared__ uint32_t lds_cols[(JADE_LDS_STACK + JADE_LDS_FIFO + JADE_LDS_STATE) * JADE_TRACE_BLOCK];
   const int lane = threadIdx.x & 63;
   const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
   LdsStack stk;
@@ -474,26 +474,28 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
       }
     }
     if (n_idle == 64 && queue_empty) break;  // nothing in flight, nothing left to claim (results are written: 64 >= REFILL_MIN)
-    // ---- one traversal unit per lane
-    bool fin = false, c1 = false, c2 = false, tested = false;
-#if JADE_PHASED
-    {  // one kind of unit per iteration: whichever advances more lanes per instruction issued
-      const bool wt = active && ray_in_leaf(r), wn = active && !ray_in_leaf(r);
-      const int nt = __popcll(__ballot(wt)), nn = __popcll(__ballot(wn));
-      if (JADE_COST_TRI * nn >= JADE_COST_NODE * nt) {
-        if (wn) fin = !ray_step_node(r, S, stk, &c1, &c2);
+    // ---- one kind of work per iteration, for every lane that has some of it: node walk or
+    // triangle tests (jade_trace.h).  The kind that advances more lanes per instruction issued runs.
+    {
+      const bool cw = active && ray_can_walk(r), ct = active && ray_can_test(r);
+      const int nw = __popcll(__ballot(cw)), nt = __popcll(__ballot(ct));
+      if (JADE_COST_TRI * nw >= JADE_COST_NODE * nt) {
+#pragma nounroll
+        for (int rep = 0; rep < JADE_STEPS_PER_PICK; ++rep) {
+          bool c1 = false, c2 = false;
+          if (active && ray_can_walk(r)) ray_step_node(r, S, stk, &c1, &c2);
+          V += (uint32_t)__popcll(__ballot(c1)) + (uint32_t)__popcll(__ballot(c2));
+        }
       } else {
-        if (wt) fin = !ray_step_tri(r, S, stk, &tested);
+#pragma nounroll
+        for (int rep = 0; rep < JADE_STEPS_PER_PICK; ++rep) {
+          bool tested = false;
+          if (active && ray_can_test(r)) ray_step_tri(r, S, stk, &tested);
+          T += (uint32_t)__popcll(__ballot(tested));
+        }
       }
     }
-#else
-    if (active) {
-      if (ray_in_leaf(r)) fin = !ray_step_tri(r, S, stk, &tested);
-      else fin = !ray_step_node(r, S, stk, &c1, &c2);
-    }
-#endif
-    V += (uint32_t)__popcll(__ballot(c1)) + (uint32_t)__popcll(__ballot(c2));
-    T += (uint32_t)__popcll(__ballot(tested));
+    const bool fin = active && ray_done(r);
     if (fin) {
       active = false;
       wb = true;

@@ -38,6 +38,18 @@ struct TraceHit {
   jvec3 point;
 };
 
+// Development ablations (cdna_hip_programming.md rule 17): JADE_ABLATE_* repeat a
+// piece of work without changing any result, to price that piece.  Off in product builds.
+#ifndef JADE_ABLATE_TRI
+#define JADE_ABLATE_TRI 0
+#endif
+#ifndef JADE_ABLATE_HIT
+#define JADE_ABLATE_HIT 0
+#endif
+#ifndef JADE_ABLATE_SLAB
+#define JADE_ABLATE_SLAB 0
+#endif
+
 // A lane's column of LDS words, lds[word * JADE_TRACE_BLOCK + tid] (bank-conflict free):
 // words [0, JADE_LDS_STACK) are the traversal stack, the JADE_LDS_STATE words after it hold
 // the parts of the ray state that the triangle test does not read (see RayState).
@@ -46,8 +58,12 @@ struct LdsStack {
   uint32_t* spill;     // global, spill[(level - JADE_LDS_STACK) * stride + gtid]
   uint32_t stride_spill;
 };
-enum { LW_INVX = JADE_LDS_STACK, LW_INVY, LW_INVZ, LW_BEST_DIST, LW_BEST_INDEX, LW_PX, LW_PY, LW_PZ, LW_END };
-static_assert(LW_END - JADE_LDS_STACK == JADE_LDS_STATE, "JADE_LDS_STATE must count the LW_* state words");
+enum {
+  LW_FIFO = JADE_LDS_STACK,  // JADE_LDS_FIFO leaf cursors waiting for their triangle tests (ring)
+  LW_INVX = JADE_LDS_STACK + JADE_LDS_FIFO, LW_INVY, LW_INVZ, LW_BEST_DIST, LW_BEST_INDEX, LW_PX, LW_PY, LW_PZ, LW_END
+};
+static_assert(LW_END - LW_INVX == JADE_LDS_STATE, "JADE_LDS_STATE must count the LW_* state words");
+static_assert((JADE_LDS_FIFO & (JADE_LDS_FIFO - 1)) == 0, "JADE_LDS_FIFO must be a power of two");
 
 static __device__ __forceinline__ void lds_put(const LdsStack& s, int word, uint32_t v) { s.lds[word * JADE_TRACE_BLOCK] = v; }
 static __device__ __forceinline__ uint32_t lds_get(const LdsStack& s, int word) { return s.lds[word * JADE_TRACE_BLOCK]; }
@@ -110,6 +126,16 @@ static __device__ __forceinline__ bool tri_test(jvec3 p1, jvec3 p2, jvec3 p3, jv
     float rate_b = jade_fma(eb.x, q.y, (-eb.y) * q.x) / divider;
     jvec3 P = jv_add(jv_add(p1, jv_scale(jv_sub(p2, p1), rate_a)), jv_scale(jv_sub(p3, p1), rate_b));
     float distance = jv_dot(jv_sub(P, o), dn);
+#if JADE_ABLATE_HIT
+    {  // the same block again on nudged operands: prices the hit path
+      jvec3 q2 = jv_sub(jv(o.x + 1e-30f, o.y, o.z), sa);
+      float ra2 = jade_diffprod(ec.y, q2.x, ec.x, q2.y) / divider;
+      float rb2 = jade_fma(eb.x, q2.y, (-eb.y) * q2.x) / divider;
+      jvec3 P2 = jv_add(jv_add(p1, jv_scale(jv_sub(p2, p1), ra2)), jv_scale(jv_sub(p3, p1), rb2));
+      float d2 = jv_dot(jv_sub(P2, o), dn);
+      asm volatile("" ::"v"(d2));
+    }
+#endif
     if (distance > 0) {
       *dist_out = distance;
       *point_out = P;
@@ -121,28 +147,39 @@ static __device__ __forceinline__ bool tri_test(jvec3 p1, jvec3 p2, jvec3 p3, jv
 
 static __device__ __forceinline__ bool finite_f(float x) { return (jade_f2u(x) & 0x7f800000u) != 0x7f800000u; }
 
-// One lane's traversal state for hitBVH (PathTrace.cu:795-859), advanced one small unit per
-// call: either one internal-node visit (both children's slab tests, near-first descent, far
-// child pushed) or one triangle test of the current leaf.  Keeping the unit of work small is
-// what lets a 64-lane wave mix lanes that are deep in a leaf with lanes that are still
-// descending without one serialising the other, and lets finished lanes be refilled.
+// One lane's traversal state for hitBVH (PathTrace.cu:795-859).
 //
-// The kernel is latency-bound, so what matters is how many waves a SIMD holds: the state is cut
-// to what fits 64 VGPRs (8 waves).  In registers: o, normalize(d), the skip index, the
-// cursor and the stack pointer.  In the lane's LDS column: 1/d (read by node visits only) and
-// the best hit so far (touched only when a triangle is actually hit).  The leaf cursor IS the
-// leaf reference: LEAF | 3 * first << 4 | count.  Bits 4-30 are the byte offset of the next
-// triangle's 48-B vertex record, so a step needs one AND to address it and +47 to advance
-// (offset + 48, count - 1); triangles are identified by that offset until the ray ends.
+// The reference never prunes against the best hit, so WHICH nodes and leaves a ray visits does
+// not depend on any triangle test: the node walk and the triangle tests are two independent
+// streams of work, joined only by the order in which leaves are met (strict "<" keeps the
+// first of two equal distances, so leaves must be tested in the order the walk meets them).
+// A lane therefore walks nodes without ever stopping at a leaf — a leaf it meets goes into a
+// small FIFO of leaf cursors — and tests triangles from the head of that FIFO.  A wave
+// iteration runs ONE of the two kinds of work for all the lanes that have some of it
+// (k_trace picks the kind with more lanes), which a lane that still walks nodes and also has
+// leaves waiting can always join.  The kernel is VALU-bound: with the kinds interleaved per
+// lane, as in a plain loop over hitBVH, each instruction runs for about a third of the lanes.
+//
+// State is cut to what fits 64 VGPRs (8 waves/SIMD).  In registers: o, normalize(d), the skip
+// offset, the node cursor, the leaf cursor, and one word of counters (stack pointer, FIFO
+// head, FIFO count).  In the lane's LDS column: the stack, the FIFO, 1/d (read by node visits
+// only) and the best hit so far (touched only when a triangle is actually hit).
+// A leaf cursor is the leaf reference itself: LEAF | 3 * first << 4 | count.  Bits 4-30 are the
+// byte offset of the next triangle's 48-B vertex record, so a test needs one AND to address it
+// and +47 to advance (offset + 48, count - 1); triangles are identified by that offset until
+// the ray ends.
 struct V3ld {
   float x, y, z;
 };
 struct RayState {
   jvec3 o, dn;
   uint32_t skipx;  // bit 31: a component of o or 1/d is not finite (NaN-faithful slab needed); bits 0-30: 48 * source triangle, 0x7fffffff = none
-  uint32_t cur;    // internal-node ref, or leaf cursor
-  int sp;
+  uint32_t cur;    // node walk: internal-node ref, a leaf ref not yet queued, or JADE_REF_NONE = walk finished
+  uint32_t leaf;   // triangle tests: cursor of the leaf being tested, 0 = none (then the FIFO is empty too)
+  uint32_t ctl;    // bits 0-7 stack pointer, 8-15 FIFO head, 16-23 FIFO count
 };
+#define RS_SP(r) ((r).ctl & 0xffu)
+#define RS_FIFO_N(r) (((r).ctl >> 16) & 0xffu)
 
 static __device__ __forceinline__ void ray_begin(RayState& r, const LdsStack& stk, const DevScene& S, jvec3 o, jvec3 d, int32_t skip) {
   r.o = o;
@@ -150,7 +187,8 @@ static __device__ __forceinline__ void ray_begin(RayState& r, const LdsStack& st
   r.dn = jv_normalize(d);
   const bool exact = !(finite_f(inv.x) && finite_f(inv.y) && finite_f(inv.z)) || !finite_f(o.x) || !finite_f(o.y) || !finite_f(o.z);
   r.skipx = (skip < 0 ? 0x7fffffffu : (uint32_t)skip * 48u) | (exact ? 0x80000000u : 0u);
-  r.sp = 0;
+  r.ctl = 0;
+  r.leaf = 0;
   r.cur = S.root_ref;
   lds_putf(stk, LW_INVX, inv.x);
   lds_putf(stk, LW_INVY, inv.y);
@@ -159,21 +197,32 @@ static __device__ __forceinline__ void ray_begin(RayState& r, const LdsStack& st
   lds_put(stk, LW_BEST_INDEX, 0xffffffffu);
 }
 
-// Make the top of the stack current; returns false when the stack is empty (ray finished).
-static __device__ __forceinline__ bool ray_pop(RayState& r, const LdsStack& stk) {
-  if (r.sp == 0) return false;
-  r.cur = stack_pop(stk, --r.sp);
-  return true;
+static __device__ __forceinline__ bool ray_walking(const RayState& r) { return r.cur != JADE_REF_NONE; }
+static __device__ __forceinline__ bool ray_done(const RayState& r) { return r.cur == JADE_REF_NONE && r.leaf == 0; }
+// room for one more leaf cursor
+static __device__ __forceinline__ bool leaf_room(const RayState& r) { return r.leaf == 0 || RS_FIFO_N(r) < JADE_LDS_FIFO; }
+// a lane can take part in a node iteration / a triangle iteration
+static __device__ __forceinline__ bool ray_can_walk(const RayState& r) {
+  return r.cur != JADE_REF_NONE && (!(r.cur & JADE_REF_LEAF) || leaf_room(r));
 }
+static __device__ __forceinline__ bool ray_can_test(const RayState& r) { return r.leaf != 0; }
 
-// Development ablations (cdna_hip_programming.md rule 17): JADE_ABLATE_* repeat a
-// piece of work without changing any result, to price that piece.  Off in product builds.
-#ifndef JADE_ABLATE_TRI
-#define JADE_ABLATE_TRI 0
-#endif
-#ifndef JADE_ABLATE_SLAB
-#define JADE_ABLATE_SLAB 0
-#endif
+// the walk's next reference: top of the stack, or JADE_REF_NONE when it is empty
+static __device__ __forceinline__ uint32_t walk_pop(RayState& r, const LdsStack& stk) {
+  if (RS_SP(r) == 0) return JADE_REF_NONE;
+  r.ctl -= 1u;
+  return stack_pop(stk, (int)RS_SP(r));
+}
+static __device__ __forceinline__ void leaf_queue(RayState& r, const LdsStack& stk, uint32_t ref) {
+  if ((ref & 15u) == 0) return;  // empty leaf: cannot happen for a valid BVH
+  if (r.leaf == 0) {
+    r.leaf = ref;
+  } else {
+    const uint32_t slot = ((r.ctl >> 8) + (r.ctl >> 16)) & (JADE_LDS_FIFO - 1);
+    lds_put(stk, LW_FIFO + (int)slot, ref);
+    r.ctl += 1u << 16;
+  }
+}
 
 static __device__ __forceinline__ int32_t ray_best_index(const LdsStack& stk) {
   const uint32_t off = lds_get(stk, LW_BEST_INDEX);  // byte offset of the vertex record, or ~0
@@ -183,77 +232,94 @@ static __device__ __forceinline__ jvec3 ray_hit_point(const LdsStack& stk) {
   return jv(lds_getf(stk, LW_PX), lds_getf(stk, LW_PY), lds_getf(stk, LW_PZ));
 }
 
-static __device__ __forceinline__ bool ray_in_leaf(const RayState& r) { return (r.cur & JADE_REF_LEAF) != 0; }
-
-// The next triangle of the current leaf (hitArray, PathTrace.cu:776-792), in index order.
-// *tested: this lane ran an intersection test (the skipped source triangle does not count).
-static __device__ __forceinline__ bool ray_step_tri(RayState& r, const DevScene& S, const LdsStack& stk, bool* tested) {
-  if (r.cur & 15u) {
-    const uint32_t off = r.cur & 0x7ffffff0u;
-    // saddr + 32-bit voffset loads; three 12-B loads: the pad word of each vertex is never brought into a register
-    const char* t0 = reinterpret_cast<const char*>(S.tverts) + off;
-    const V3ld a0 = *reinterpret_cast<const V3ld*>(t0), b0 = *reinterpret_cast<const V3ld*>(t0 + 16),
-               c0 = *reinterpret_cast<const V3ld*>(t0 + 32);
-    r.cur += 47u;  // next record, count - 1
+// One triangle of the leaf at the head of the FIFO (hitArray, PathTrace.cu:776-792), in index order.
+// Call only if ray_can_test.  *tested: an intersection test ran (the skipped source triangle does not count).
+static __device__ __forceinline__ void ray_step_tri(RayState& r, const DevScene& S, const LdsStack& stk, bool* tested) {
+  const uint32_t off = r.leaf & 0x7ffffff0u;
+  // saddr + 32-bit voffset loads; three 12-B loads: the pad word of each vertex is never brought into a register
+  const char* t0 = reinterpret_cast<const char*>(S.tverts) + off;
+  const V3ld a0 = *reinterpret_cast<const V3ld*>(t0), b0 = *reinterpret_cast<const V3ld*>(t0 + 16),
+             c0 = *reinterpret_cast<const V3ld*>(t0 + 32);
+  r.leaf += 47u;  // next record, count - 1
 #if JADE_ABLATE_TRI
-    {
-      float d2; jvec3 P2;
-      jvec3 o2 = jv(r.o.x + 1e-30f, r.o.y, r.o.z);
-      bool h2 = tri_test(jv(a0.x, a0.y, a0.z), jv(b0.x, b0.y, b0.z), jv(c0.x, c0.y, c0.z), o2, r.dn, &d2, &P2);
-      asm volatile("" ::"v"(h2 ? d2 + P2.x : 0.0f));
-    }
+  {
+    float d2; jvec3 P2;
+    jvec3 o2 = jv(r.o.x + 1e-30f, r.o.y, r.o.z);
+    bool h2 = tri_test(jv(a0.x, a0.y, a0.z), jv(b0.x, b0.y, b0.z), jv(c0.x, c0.y, c0.z), o2, r.dn, &d2, &P2);
+    asm volatile("" ::"v"(h2 ? d2 + P2.x : 0.0f));
+  }
 #endif
-    if (off != (r.skipx & 0x7fffffffu)) {
-      *tested = true;
-      float dist;
-      jvec3 P;
-      if (tri_test(jv(a0.x, a0.y, a0.z), jv(b0.x, b0.y, b0.z), jv(c0.x, c0.y, c0.z), r.o, r.dn, &dist, &P) &&
-          dist < lds_getf(stk, LW_BEST_DIST)) {
-        lds_putf(stk, LW_BEST_DIST, dist);
-        lds_put(stk, LW_BEST_INDEX, off);
-        lds_putf(stk, LW_PX, P.x);
-        lds_putf(stk, LW_PY, P.y);
-        lds_putf(stk, LW_PZ, P.z);
-      }
+  if (off != (r.skipx & 0x7fffffffu)) {
+    *tested = true;
+    float dist;
+    jvec3 P;
+    if (tri_test(jv(a0.x, a0.y, a0.z), jv(b0.x, b0.y, b0.z), jv(c0.x, c0.y, c0.z), r.o, r.dn, &dist, &P) &&
+        dist < lds_getf(stk, LW_BEST_DIST)) {
+      lds_putf(stk, LW_BEST_DIST, dist);
+      lds_put(stk, LW_BEST_INDEX, off);
+      lds_putf(stk, LW_PX, P.x);
+      lds_putf(stk, LW_PY, P.y);
+      lds_putf(stk, LW_PZ, P.z);
     }
   }
-  if (r.cur & 15u) return true;
-  return ray_pop(r, stk);  // leaf finished (or empty: cannot happen for a valid BVH)
+  if ((r.leaf & 15u) == 0) {  // leaf finished: next one from the FIFO
+    if (RS_FIFO_N(r)) {
+      const uint32_t head = (r.ctl >> 8) & 0xffu;
+      r.leaf = lds_get(stk, LW_FIFO + (int)head);
+      r.ctl = (r.ctl & 0xffff00ffu) - (1u << 16) + (((head + 1u) & (JADE_LDS_FIFO - 1)) << 8);
+    } else {
+      r.leaf = 0;
+    }
+  }
 }
 
-// One internal node.  *c1, *c2: the child exists (its record counts as visited).
-static __device__ __forceinline__ bool ray_step_node(RayState& r, const DevScene& S, const LdsStack& stk, bool* c1, bool* c2) {
-  const float4* nd = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.nodes) + r.cur * 64u);
-  const float4 a = nd[0], b = nd[1], c = nd[2];
-  const uint2 rf = *reinterpret_cast<const uint2*>(nd + 3);
-  const jvec3 inv = jv(lds_getf(stk, LW_INVX), lds_getf(stk, LW_INVY), lds_getf(stk, LW_INVZ));
-  const bool exact = (int32_t)r.skipx < 0;
-  float d1 = -1.0f, d2 = -1.0f;
+// One unit of the node walk.  Call only if ray_can_walk.  A leaf reference in `cur` is queued and
+// replaced by the next reference; an internal node is visited: both children's slab tests,
+// near-first descent (PathTrace.cu:835-848), the far child pushed.  *c1, *c2: the child exists (its
+// record counts as visited).
+static __device__ __forceinline__ void ray_step_node(RayState& r, const DevScene& S, const LdsStack& stk, bool* c1, bool* c2) {
+  if (r.cur & JADE_REF_LEAF) {  // a leaf left over from a step that found the FIFO full (room was checked by ray_can_walk)
+    leaf_queue(r, stk, r.cur);
+    r.cur = walk_pop(r, stk);
+  }
+  if (r.cur != JADE_REF_NONE && !(r.cur & JADE_REF_LEAF)) {
+    const float4* nd = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.nodes) + r.cur * 64u);
+    const float4 a = nd[0], b = nd[1], c = nd[2];
+    const uint2 rf = *reinterpret_cast<const uint2*>(nd + 3);
+    const jvec3 inv = jv(lds_getf(stk, LW_INVX), lds_getf(stk, LW_INVY), lds_getf(stk, LW_INVZ));
+    const bool exact = (int32_t)r.skipx < 0;
+    float d1 = -1.0f, d2 = -1.0f;
 #if JADE_ABLATE_SLAB
-  {
-    jvec3 o2 = jv(r.o.x + 1e-30f, r.o.y, r.o.z);
-    float e1 = slab(o2, inv, a.x, a.y, a.z, a.w, b.x, b.y, exact), e2 = slab(o2, inv, b.z, b.w, c.x, c.y, c.z, c.w, exact);
-    asm volatile("" ::"v"(e1 + e2));
-  }
+    {
+      jvec3 o2 = jv(r.o.x + 1e-30f, r.o.y, r.o.z);
+      float e1 = slab(o2, inv, a.x, a.y, a.z, a.w, b.x, b.y, exact), e2 = slab(o2, inv, b.z, b.w, c.x, c.y, c.z, c.w, exact);
+      asm volatile("" ::"v"(e1 + e2));
+    }
 #endif
-  if (rf.x != JADE_REF_NONE) {
-    *c1 = true;
-    d1 = slab(r.o, inv, a.x, a.y, a.z, a.w, b.x, b.y, exact);
+    if (rf.x != JADE_REF_NONE) {
+      *c1 = true;
+      d1 = slab(r.o, inv, a.x, a.y, a.z, a.w, b.x, b.y, exact);
+    }
+    if (rf.y != JADE_REF_NONE) {
+      *c2 = true;
+      d2 = slab(r.o, inv, b.z, b.w, c.x, c.y, c.z, c.w, exact);
+    }
+    const bool in1 = d1 > 0, in2 = d2 > 0;
+    if (in1 && in2) {
+      const bool first = d1 < d2;
+      stack_push(stk, (int)RS_SP(r), first ? rf.y : rf.x);  // the far child
+      r.ctl += 1u;
+      r.cur = first ? rf.x : rf.y;
+    } else if (in1 || in2) {
+      r.cur = in1 ? rf.x : rf.y;
+    } else {
+      r.cur = walk_pop(r, stk);
+    }
   }
-  if (rf.y != JADE_REF_NONE) {
-    *c2 = true;
-    d2 = slab(r.o, inv, b.z, b.w, c.x, c.y, c.z, c.w, exact);
+  // a leaf met by this step is queued at once (it is not worth an iteration of its own);
+  // one that does not fit stays in `cur` until triangle tests have made room
+  if ((r.cur & JADE_REF_LEAF) && leaf_room(r)) {
+    leaf_queue(r, stk, r.cur);
+    r.cur = walk_pop(r, stk);
   }
-  const bool in1 = d1 > 0, in2 = d2 > 0;
-  if (in1 && in2) {  // near child first (d1 < d2, PathTrace.cu:835-848): follow it, push the far one
-    const bool first = d1 < d2;
-    stack_push(stk, r.sp++, first ? rf.y : rf.x);
-    r.cur = first ? rf.x : rf.y;
-    return true;
-  }
-  if (in1 || in2) {
-    r.cur = in1 ? rf.x : rf.y;
-    return true;
-  }
-  return ray_pop(r, stk);
 }
