@@ -4,17 +4,20 @@
 // layouts (Triangle_cu 112 B, BVHNode_cu 40 B).  The traversal kernel does not
 // read those: jade_scene_create re-lays the geometry out as
 //
-//   node records   64 B per INTERNAL node, children's boxes stored in the
-//                  parent:  float4 {L.aa.xyz, L.bb.x} {L.bb.yz, R.aa.xy}
-//                  {R.aa.z, R.bb.xyz} + uint4 {left_ref, right_ref, 0, 0}
-//                  -> one visit = 4 x 16-B loads from one 64-B aligned line,
-//                  instead of the reference's 3 x 40-B records (parent, and
-//                  each child read again when popped: PathTrace.cu:809/826/830)
+//   node records   64 B per INTERNAL node, children's boxes stored in the parent and
+//                  interleaved so that the same coordinate of the left and the right box
+//                  is one aligned register pair (the two slab tests run as packed fp32):
+//                  float4 {L.aa.x, R.aa.x, L.aa.y, R.aa.y} {L.aa.z, R.aa.z, L.bb.x, R.bb.x}
+//                  {L.bb.y, R.bb.y, L.bb.z, R.bb.z} + uint4 {left_ref, right_ref, 0, 0}
+//                  -> one visit = 4 loads from one 64-B aligned line, instead of the
+//                  reference's 3 x 40-B records (parent, and each child read again when
+//                  popped: PathTrace.cu:809/826/830)
 //   child refs     internal: index into the compacted node array;
-//                  leaf: 0x80000000 | first_triangle << 4 | n  (n <= 15);
+//                  leaf: 0x80000000 | 3 * first_triangle << 4 | n  (n <= 15);
 //                  JADE_REF_NONE for the reference's "child 0"
-//   vertex records 48 B per triangle: three float4 {p.xyz, pad}; the 76 B of
-//                  material data never enter the traversal cache footprint
+//   vertex records 48 B per triangle, p1 and p2 interleaved for the same reason:
+//                  {p1.x, p2.x, p1.y, p2.y} {p1.z, p2.z, p3.x, p3.y} {p3.z, pad x3};
+//                  the 76 B of material data never enter the traversal cache footprint
 //
 // Shading reads the untouched 112-B records (they are needed once per
 // shaded vertex, not once per intersection test).

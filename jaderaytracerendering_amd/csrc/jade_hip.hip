@@ -711,18 +711,18 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
     if (nd.left > 0) { memcpy(la, d->nodes[nd.left].aa, 12); memcpy(lb, d->nodes[nd.left].bb, 12); }
     if (nd.right > 0) { memcpy(ra, d->nodes[nd.right].aa, 12); memcpy(rb, d->nodes[nd.right].bb, 12); }
     float4* o = &nodes[(size_t)4 * compact[i]];
-    o[0] = make_float4(la[0], la[1], la[2], lb[0]);
-    o[1] = make_float4(lb[1], lb[2], ra[0], ra[1]);
-    o[2] = make_float4(ra[2], rb[0], rb[1], rb[2]);
+    o[0] = make_float4(la[0], ra[0], la[1], ra[1]);
+    o[1] = make_float4(la[2], ra[2], lb[0], rb[0]);
+    o[2] = make_float4(lb[1], rb[1], lb[2], rb[2]);
     uint32_t refs[4] = {ref_of(nd.left), ref_of(nd.right), 0u, 0u};
     memcpy(&o[3], refs, 16);
   }
   std::vector<float4> tverts((size_t)3 * d->n_triangles);
   for (int i = 0; i < d->n_triangles; ++i) {
     const jade_triangle& t = d->triangles[i];
-    tverts[3 * (size_t)i] = make_float4(t.p1[0], t.p1[1], t.p1[2], 0.0f);
-    tverts[3 * (size_t)i + 1] = make_float4(t.p2[0], t.p2[1], t.p2[2], 0.0f);
-    tverts[3 * (size_t)i + 2] = make_float4(t.p3[0], t.p3[1], t.p3[2], 0.0f);
+    tverts[3 * (size_t)i] = make_float4(t.p1[0], t.p2[0], t.p1[1], t.p2[1]);
+    tverts[3 * (size_t)i + 1] = make_float4(t.p1[2], t.p2[2], t.p3[0], t.p3[1]);
+    tverts[3 * (size_t)i + 2] = make_float4(t.p3[2], 0.0f, 0.0f, 0.0f);
   }
 
   jade_scene* s = new (std::nothrow) jade_scene();

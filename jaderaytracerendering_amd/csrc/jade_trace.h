@@ -79,14 +79,32 @@ static __device__ __forceinline__ uint32_t stack_pop(const LdsStack& s, int sp) 
   return s.spill[(size_t)(sp - JADE_LDS_STACK) * s.stride_spill];
 }
 
-// hitAABB, PathTrace.cu:758-771, with 1/dir hoisted.  `exact` selects the
-// NaN-faithful ternary form; it is only needed when a component of 1/dir is
-// not finite (0 * inf is the one way a NaN can appear for a finite scene),
-// otherwise v_min/v_max give bit-identical slab values.
-static __device__ __forceinline__ float slab(jvec3 o, jvec3 inv, float ax, float ay, float az, float bx, float by,
-                                             float bz, bool exact) {
-  float fx = (bx - o.x) * inv.x, fy = (by - o.y) * inv.y, fz = (bz - o.z) * inv.z;
-  float nx = (ax - o.x) * inv.x, ny = (ay - o.y) * inv.y, nz = (az - o.z) * inv.z;
+// Two lanes of packed fp32 (v_pk_add/mul/fma_f32: full rate, IEEE per component, so the
+// values are those of the scalar statements).  The kernel is VALU-bound; the left/right slab
+// tests and the projections of p1/p2 are the same statements on two operands.
+typedef float f2 __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ f2 f2s(float s) { return f2{s, s}; }
+// The ray's origin and unit direction travel as three aligned register pairs, (o.x, o.y) (o.z, dn.x)
+// (dn.y, dn.z): a packed instruction broadcasts either half of a pair through op_sel, so no
+// component ever has to be copied next to itself.
+struct RayOD {
+  f2 a, b, c;
+};
+#define OD_OX(q) __builtin_shufflevector((q).a, (q).a, 0, 0)
+#define OD_OY(q) __builtin_shufflevector((q).a, (q).a, 1, 1)
+#define OD_OZ(q) __builtin_shufflevector((q).b, (q).b, 0, 0)
+#define OD_DX(q) __builtin_shufflevector((q).b, (q).b, 1, 1)
+#define OD_DY(q) __builtin_shufflevector((q).c, (q).c, 0, 0)
+#define OD_DZ(q) __builtin_shufflevector((q).c, (q).c, 1, 1)
+static __device__ __forceinline__ jvec3 od_o(const RayOD& q) { return jv(q.a.x, q.a.y, q.b.x); }
+static __device__ __forceinline__ jvec3 od_dn(const RayOD& q) { return jv(q.b.y, q.c.x, q.c.y); }
+static __device__ __forceinline__ f2 f2fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// hitAABB, PathTrace.cu:758-771, with 1/dir hoisted: the reduction of one box from its six
+// slab values.  `exact` selects the NaN-faithful ternary form; it is only needed when a
+// component of 1/dir or of the origin is not finite (0 * inf is the one way a NaN can appear
+// for a finite scene), otherwise v_min/v_max give bit-identical slab values.
+static __device__ __forceinline__ float slab_reduce(float fx, float fy, float fz, float nx, float ny, float nz, bool exact) {
   float t0, t1;
   if (exact) {
     float tmaxx = fx > nx ? fx : nx, tmaxy = fy > ny ? fy : ny, tmaxz = fz > nz ? fz : nz;
@@ -108,18 +126,38 @@ static __device__ __forceinline__ float slab(jvec3 o, jvec3 inv, float ax, float
   }
   return (t1 >= t0) ? ((t0 > 0.0f) ? t0 : t1) : -1.0f;
 }
+// both children of a node record (jade_device.h): lane .x = left box, .y = right box
+static __device__ __forceinline__ void slab2(const RayOD& od, jvec3 inv, float4 q0, float4 q1, float4 q2, bool exact, float* d1, float* d2) {
+  const f2 ax = {q0.x, q0.y}, ay = {q0.z, q0.w}, az = {q1.x, q1.y}, bx = {q1.z, q1.w}, by = {q2.x, q2.y}, bz = {q2.z, q2.w};
+  const f2 fx = (bx - OD_OX(od)) * f2s(inv.x), fy = (by - OD_OY(od)) * f2s(inv.y), fz = (bz - OD_OZ(od)) * f2s(inv.z);
+  const f2 nx = (ax - OD_OX(od)) * f2s(inv.x), ny = (ay - OD_OY(od)) * f2s(inv.y), nz = (az - OD_OZ(od)) * f2s(inv.z);
+  *d1 = slab_reduce(fx.x, fy.x, fz.x, nx.x, ny.x, nz.x, exact);
+  *d2 = slab_reduce(fx.y, fy.y, fz.y, nx.y, ny.y, nz.y, exact);
+}
 
-// hitTriangle, PathTrace.cu:705-754, with normalize(dir) hoisted.
-static __device__ __forceinline__ bool tri_test(jvec3 p1, jvec3 p2, jvec3 p3, jvec3 o, jvec3 dn, float* dist_out,
-                                                jvec3* point_out) {
-  jvec3 sa = jv_sub(p1, jv_scale(dn, jv_dot(dn, jv_sub(p1, o))));
-  jvec3 sb = jv_sub(p2, jv_scale(dn, jv_dot(dn, jv_sub(p2, o))));
-  jvec3 sc = jv_sub(p3, jv_scale(dn, jv_dot(dn, jv_sub(p3, o))));
-  jvec3 pa = jv_sub(sa, o), pb = jv_sub(sb, o), pc = jv_sub(sc, o);
-  float papb = jv_mixed(dn, pa, pb);
-  float pbpc = jv_mixed(dn, pb, pc);
-  float pcpa = jv_mixed(dn, pc, pa);
+// hitTriangle, PathTrace.cu:705-754, with normalize(dir) hoisted.  The vertex record comes as
+// loaded (jade_device.h): q0 = {p1.x, p2.x, p1.y, p2.y}, q1 = {p1.z, p2.z}, p3 apart.  Lane .x of
+// every pair is the statement for p1 (or for papb), lane .y the same statement for p2 (pbpc).
+static __device__ __forceinline__ bool tri_test(float4 q0, float2 q1, jvec3 p3, const RayOD& od, float* dist_out, jvec3* point_out) {
+  const jvec3 o = od_o(od), dn = od_dn(od);
+  const f2 Ax = {q0.x, q0.y}, Ay = {q0.z, q0.w}, Az = {q1.x, q1.y};
+  // sa|sb = p - dn * dot(dn, p - o)    (jv_dot: fma(a.z, b.z, fma(a.y, b.y, a.x * b.x)))
+  const f2 tA = f2fma(OD_DZ(od), Az - OD_OZ(od), f2fma(OD_DY(od), Ay - OD_OY(od), OD_DX(od) * (Ax - OD_OX(od))));
+  const f2 sx = Ax - OD_DX(od) * tA, sy = Ay - OD_DY(od) * tA, sz = Az - OD_DZ(od) * tA;
+  const jvec3 sc = jv_sub(p3, jv_scale(dn, jv_dot(dn, jv_sub(p3, o))));
+  // pa|pb = s - o, pc
+  const f2 px = sx - OD_OX(od), py = sy - OD_OY(od), pz = sz - OD_OZ(od);
+  const jvec3 pc = jv_sub(sc, o);
+  // papb|pbpc = mixed(dn, pa|pb, pb|pc)   (jv_mixed / jade_diffprod: fma(a, b, -(c * d)))
+  const f2 cx = {px.y, pc.x}, cy = {py.y, pc.y}, cz = {pz.y, pc.z};
+  f2 m = OD_DX(od) * f2fma(py, cz, -(pz * cy));
+  m = f2fma(OD_DY(od), f2fma(pz, cx, -(px * cz)), m);
+  m = f2fma(OD_DZ(od), f2fma(px, cy, -(py * cx)), m);
+  const float papb = m.x, pbpc = m.y;
+  const float pcpa = jv_mixed(dn, pc, jv(px.x, py.x, pz.x));
   if ((papb > 0 && pbpc > 0 && pcpa > 0) || (papb < 0 && pbpc < 0 && pcpa < 0)) {
+    const jvec3 p1 = jv(q0.x, q0.z, q1.x), p2 = jv(q0.y, q0.w, q1.y);
+    const jvec3 sa = jv(sx.x, sy.x, sz.x), sb = jv(sx.y, sy.y, sz.y);
     jvec3 eb = jv_sub(sb, sa), ec = jv_sub(sc, sa), q = jv_sub(o, sa);
     float divider = jade_diffprod(eb.x, ec.y, eb.y, ec.x);
     float rate_a = jade_diffprod(ec.y, q.x, ec.x, q.y) / divider;
@@ -172,7 +210,7 @@ struct V3ld {
   float x, y, z;
 };
 struct RayState {
-  jvec3 o, dn;
+  RayOD od;        // origin and normalize(d)
   uint32_t skipx;  // bit 31: a component of o or 1/d is not finite (NaN-faithful slab needed); bits 0-30: 48 * source triangle, 0x7fffffff = none
   uint32_t cur;    // node walk: internal-node ref, a leaf ref not yet queued, or JADE_REF_NONE = walk finished
   uint32_t leaf;   // triangle tests: cursor of the leaf being tested, 0 = none (then the FIFO is empty too)
@@ -182,9 +220,11 @@ struct RayState {
 #define RS_FIFO_N(r) (((r).ctl >> 16) & 0xffu)
 
 static __device__ __forceinline__ void ray_begin(RayState& r, const LdsStack& stk, const DevScene& S, jvec3 o, jvec3 d, int32_t skip) {
-  r.o = o;
   const jvec3 inv = jv(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-  r.dn = jv_normalize(d);
+  const jvec3 dn = jv_normalize(d);
+  r.od.a = f2{o.x, o.y};
+  r.od.b = f2{o.z, dn.x};
+  r.od.c = f2{dn.y, dn.z};
   const bool exact = !(finite_f(inv.x) && finite_f(inv.y) && finite_f(inv.z)) || !finite_f(o.x) || !finite_f(o.y) || !finite_f(o.z);
   r.skipx = (skip < 0 ? 0x7fffffffu : (uint32_t)skip * 48u) | (exact ? 0x80000000u : 0u);
   r.ctl = 0;
@@ -236,16 +276,19 @@ static __device__ __forceinline__ jvec3 ray_hit_point(const LdsStack& stk) {
 // Call only if ray_can_test.  *tested: an intersection test ran (the skipped source triangle does not count).
 static __device__ __forceinline__ void ray_step_tri(RayState& r, const DevScene& S, const LdsStack& stk, bool* tested) {
   const uint32_t off = r.leaf & 0x7ffffff0u;
-  // saddr + 32-bit voffset loads; three 12-B loads: the pad word of each vertex is never brought into a register
+  // saddr + 32-bit voffset loads of the 36 used bytes of the record
   const char* t0 = reinterpret_cast<const char*>(S.tverts) + off;
-  const V3ld a0 = *reinterpret_cast<const V3ld*>(t0), b0 = *reinterpret_cast<const V3ld*>(t0 + 16),
-             c0 = *reinterpret_cast<const V3ld*>(t0 + 32);
+  const float4 q0 = *reinterpret_cast<const float4*>(t0);
+  const float2 q1 = *reinterpret_cast<const float2*>(t0 + 16);
+  const V3ld q3 = *reinterpret_cast<const V3ld*>(t0 + 24);
+  const jvec3 p3 = jv(q3.x, q3.y, q3.z);
   r.leaf += 47u;  // next record, count - 1
 #if JADE_ABLATE_TRI
   {
     float d2; jvec3 P2;
-    jvec3 o2 = jv(r.o.x + 1e-30f, r.o.y, r.o.z);
-    bool h2 = tri_test(jv(a0.x, a0.y, a0.z), jv(b0.x, b0.y, b0.z), jv(c0.x, c0.y, c0.z), o2, r.dn, &d2, &P2);
+    RayOD o2 = r.od;
+    o2.a.x += 1e-30f;
+    bool h2 = tri_test(q0, q1, p3, o2, &d2, &P2);
     asm volatile("" ::"v"(h2 ? d2 + P2.x : 0.0f));
   }
 #endif
@@ -253,7 +296,7 @@ static __device__ __forceinline__ void ray_step_tri(RayState& r, const DevScene&
     *tested = true;
     float dist;
     jvec3 P;
-    if (tri_test(jv(a0.x, a0.y, a0.z), jv(b0.x, b0.y, b0.z), jv(c0.x, c0.y, c0.z), r.o, r.dn, &dist, &P) &&
+    if (tri_test(q0, q1, p3, r.od, &dist, &P) &&
         dist < lds_getf(stk, LW_BEST_DIST)) {
       lds_putf(stk, LW_BEST_DIST, dist);
       lds_put(stk, LW_BEST_INDEX, off);
@@ -291,19 +334,18 @@ static __device__ __forceinline__ void ray_step_node(RayState& r, const DevScene
     float d1 = -1.0f, d2 = -1.0f;
 #if JADE_ABLATE_SLAB
     {
-      jvec3 o2 = jv(r.o.x + 1e-30f, r.o.y, r.o.z);
-      float e1 = slab(o2, inv, a.x, a.y, a.z, a.w, b.x, b.y, exact), e2 = slab(o2, inv, b.z, b.w, c.x, c.y, c.z, c.w, exact);
+      RayOD o2 = r.od;
+      o2.a.x += 1e-30f;
+      float e1, e2;
+      slab2(o2, inv, a, b, c, exact, &e1, &e2);
       asm volatile("" ::"v"(e1 + e2));
     }
 #endif
-    if (rf.x != JADE_REF_NONE) {
-      *c1 = true;
-      d1 = slab(r.o, inv, a.x, a.y, a.z, a.w, b.x, b.y, exact);
-    }
-    if (rf.y != JADE_REF_NONE) {
-      *c2 = true;
-      d2 = slab(r.o, inv, b.z, b.w, c.x, c.y, c.z, c.w, exact);
-    }
+    slab2(r.od, inv, a, b, c, exact, &d1, &d2);
+    *c1 = rf.x != JADE_REF_NONE;  // a missing child (the reference's index 0) is neither counted nor entered
+    *c2 = rf.y != JADE_REF_NONE;
+    if (!*c1) d1 = -1.0f;
+    if (!*c2) d2 = -1.0f;
     const bool in1 = d1 > 0, in2 = d2 > 0;
     if (in1 && in2) {
       const bool first = d1 < d2;
