@@ -32,6 +32,7 @@
 #define JADE_REF_NONE 0x7fffffffu
 #define JADE_MAX_TRIS ((1 << 27) / 3) /* leaf refs carry 48 * first_triangle in bits 4-30 (jade_trace.h) */
 #define JADE_MAX_LEAF 15
+#define JADE_SKIP_CAMERA (-2) /* PathState.skip: camera ray (no source triangle, origin = PathState.eye) */
 #define JADE_INF_F 2147483647.0f /* #define INF, PathTrace.cu:23 */
 
 #ifndef JADE_LDS_STACK
@@ -97,6 +98,7 @@ struct PathState {
   int32_t* obj;         // current vertex: triangle index
   float* src;           // [3][npix] current vertex position
   float* out;           // [3][npix] direction back toward the previous vertex
+  float eye[3];         // origin of every camera ray (skip == JADE_SKIP_CAMERA): not stored per record
   float* org;           // [3][npix] origin shared by this pixel's pending rays
   int32_t* skip;        // source triangle of the pending rays
   float* aux;           // [3][npix] BSSRDF profile / refraction attenuation

@@ -172,12 +172,21 @@ static __device__ __forceinline__ void shade_record(const DevScene& S, const Pat
     c.src = jv(0, 0, 0);
     c.out = jv(0, 0, 0);
     if (has_ctx) {
-      c.thr = ld3(P.thr, npix, p);
-      c.acc = ld3(P.acc, npix, p);
-      c.le = ld3(P.le, npix, p);
+      // Stored and loaded by need (the lean kernel is bound by these bytes): before the first
+      // path_push thr is 1 and acc 0 (only path_push changes them, and it counts depth up); a
+      // mirror ray in flight needs neither the vertex it left nor, at depth 0, a stored Le
+      // (it is the emissive of the triangle still in obj).
       c.obj = P.obj[p];
-      c.src = ld3(P.src, npix, p);
-      c.out = ld3(P.out, npix, p);
+      if (c.depth != 0) {
+        c.thr = ld3(P.thr, npix, p);
+        c.acc = ld3(P.acc, npix, p);
+      }
+      if (st == ST_MIRROR && c.depth == 0) c.le = V3(S.tris[c.obj].emissive);
+      else c.le = ld3(P.le, npix, p);
+      if (st != ST_MIRROR) {
+        c.src = ld3(P.src, npix, p);
+        c.out = ld3(P.out, npix, p);
+      }
     }
     uint32_t done = done0;
     jvec3 l_final;
@@ -260,8 +269,7 @@ static __device__ __forceinline__ void shade_record(const DevScene& S, const Pat
         float up_offset = (float)(-1.0 + R.two_over_h * ((double)fy - 0.5));
         jvec3 dir = jade_transform(jv(left_offset, up_offset, -1.5f), 0.0f, R.cam);
         dir = jv_normalize(dir);
-        st3(P.org, npix, p, jv(R.eye[0], R.eye[1], R.eye[2]));
-        P.skip[p] = -1;
+        P.skip[p] = JADE_SKIP_CAMERA;  // no source triangle, and the origin is the eye: k_trace takes it from P.eye
         px.set_dir(0, dir);
         px.set_hit(0, -1);
         c.n_emit_rays = 1;
@@ -276,12 +284,16 @@ static __device__ __forceinline__ void shade_record(const DevScene& S, const Pat
     P.done[p] = done;
     P.stage[p] = st | (c.depth << 8) | (c.flags << 16);
     if ((st >= ST_DIFFUSE && st <= ST_REFRACT_EXIT) || st == ST_VERTEX) {
-      st3(P.thr, npix, p, c.thr);
-      st3(P.acc, npix, p, c.acc);
-      st3(P.le, npix, p, c.le);
       P.obj[p] = c.obj;
-      st3(P.src, npix, p, c.src);
-      st3(P.out, npix, p, c.out);
+      if (c.depth != 0) {
+        st3(P.thr, npix, p, c.thr);
+        st3(P.acc, npix, p, c.acc);
+      }
+      if (!(st == ST_MIRROR && c.depth == 0)) st3(P.le, npix, p, c.le);
+      if (st != ST_MIRROR) {
+        st3(P.src, npix, p, c.src);
+        st3(P.out, npix, p, c.out);
+      }
     }
   }
   st_out = st;
@@ -463,10 +475,11 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
         if (!active && rank < take) {
           my_e = queue[lbase + rank];
           const uint32_t k = my_e / (uint32_t)npix, p = my_e - k * (uint32_t)npix;
-          const jvec3 o = ld3(P.org, npix, p);
+          const int32_t skip = P.skip[p];
+          const jvec3 o = skip == JADE_SKIP_CAMERA ? jv(P.eye[0], P.eye[1], P.eye[2]) : ld3(P.org, npix, p);
           const float* db = P.dir + my_e;
           const jvec3 d = jv(db[0], db[plane], db[2 * plane]);
-          ray_begin(r, stk, S, o, d, P.skip[p]);
+          ray_begin(r, stk, S, o, d, skip);
           active = true;
         }
         V += take;  // the root record of every ray started
@@ -862,6 +875,7 @@ int jade_render_begin(jade_scene* s, const jade_render_params* rp) {
   if (npix64 == 0) { s->ps.npix = 0; s->ps.npx = 0; s->have_rp = true; return JADE_OK; }
   int rc = setup_state(s, (int)npx64, rpp, nslots);
   if (rc) return rc;
+  memcpy(s->ps.eye, rp->eye, sizeof s->ps.eye);
   HIP_TRY(upload(s->b_tiles, s->tile_ids.data(), s->tile_ids.size()));
   HIP_TRY(hipMemsetAsync(s->b_ctr.p, 0, sizeof(DevCounters) * JADE_CTR_SHARDS, s->stream));
   hipLaunchKernelGGL(k_init, dim3((unsigned)((npix64 + 255) / 256)), dim3(256), 0, s->stream, s->ps);
@@ -1237,7 +1251,10 @@ int jade_trace_rays(jade_scene* s, int32_t n, const float* origins, const float*
   DevBuf b_org, b_dir, b_skip, b_hit, b_hpt, b_q, b_spill;
   HIP_TRY(upload(b_org, so.data(), so.size()));
   HIP_TRY(upload(b_dir, sd.data(), sd.size()));
-  HIP_TRY(upload(b_skip, skip, N));
+  std::vector<int32_t> sk(skip, skip + N);
+  for (int32_t& v : sk)
+    if (v < 0) v = -1;  // any negative value means "no source triangle" (the device keeps -2 for camera rays)
+  HIP_TRY(upload(b_skip, sk.data(), N));
   HIP_TRY(b_hit.alloc(N * 4));
   HIP_TRY(b_hpt.alloc(3 * N * 4));
   HIP_TRY(upload(b_q, q.data(), N));
