@@ -92,10 +92,11 @@ __global__ void k_init(PathState P) {
   P.stage[p] = ST_IDLE;
 }
 
+#define JADE_ARM_BLOCK 1024
 // Lists every record that has work in this step (samples left to start, or a
 // path suspended by a previous step): the input of the first shade pass.
-__global__ __launch_bounds__(256) void k_arm(PathState P, uint32_t target_spp, uint32_t* active_out, QueueCtl* qc) {
-  __shared__ uint32_t sh_cnt[4], sh_base;
+__global__ __launch_bounds__(JADE_ARM_BLOCK) void k_arm(PathState P, uint32_t target_spp, uint32_t* active_out, QueueCtl* qc) {
+  __shared__ uint32_t sh_cnt[JADE_ARM_BLOCK / 64], sh_base;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   bool want = false;
   if (p < P.npix) {
@@ -107,8 +108,9 @@ __global__ __launch_bounds__(256) void k_arm(PathState P, uint32_t target_spp, u
   const uint32_t off = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
   if (lane == 0) sh_cnt[w] = (uint32_t)__popcll(m);
   __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t tot = sh_cnt[0] + sh_cnt[1] + sh_cnt[2] + sh_cnt[3];
+  if (threadIdx.x == 0) {  // one list atomic per 1024 records: same-address atomics cost ~12 ns each
+    uint32_t tot = 0;
+    for (int i = 0; i < JADE_ARM_BLOCK / 64; ++i) tot += sh_cnt[i];
     sh_base = tot ? atomicAdd(&qc->active, tot) : 0u;
   }
   __syncthreads();
@@ -925,7 +927,7 @@ static int run_passes(jade_scene* s, uint32_t target_spp, double* ms_out, double
   // the records with work in this step
   uint32_t host_ctl[3] = {0, 0, 0};
   HIP_TRY(hipMemsetAsync(qc, 0, 12, s->stream));
-  hipLaunchKernelGGL(k_arm, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s->stream, s->ps, target_spp,
+  hipLaunchKernelGGL(k_arm, dim3((unsigned)((npix + JADE_ARM_BLOCK - 1) / JADE_ARM_BLOCK)), dim3(JADE_ARM_BLOCK), 0, s->stream, s->ps, target_spp,
                      s->b_active[0].as<uint32_t>(), qc);
   HIP_TRY(hipMemcpyAsync(host_ctl, qc, 12, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
@@ -947,7 +949,7 @@ static int run_passes(jade_scene* s, uint32_t target_spp, double* ms_out, double
     if (!lean_mode && !have_list) {
       cur = 0;
       HIP_TRY(hipMemsetAsync(qc, 0, 16, s->stream));
-      hipLaunchKernelGGL(k_arm, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s->stream, s->ps, target_spp,
+      hipLaunchKernelGGL(k_arm, dim3((unsigned)((npix + JADE_ARM_BLOCK - 1) / JADE_ARM_BLOCK)), dim3(JADE_ARM_BLOCK), 0, s->stream, s->ps, target_spp,
                          s->b_active[0].as<uint32_t>(), qc);
       have_list = true;
     }

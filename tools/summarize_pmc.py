@@ -22,7 +22,7 @@ for d in (fetch_dir, write_dir, l2_dir):
         agg[k][0] += 1
         agg[k][1] += float(r["Counter_Value"])
     for (kn, cn), v in agg.items():
-        if kn in ("k_trace", "k_shade"):
+        if kn in ("k_trace", "k_shade", "k_shade_lean"):
             out.setdefault(kn, {})[cn] = {"dispatches": v[0], "sum": v[1], "avg_per_launch": v[1] / v[0]}
 b = json.load(open(bench))
 t = out["k_trace"]
