@@ -18,7 +18,9 @@ value = (primary + secondary rays traced by all ranks in the K timed steps)
         / max-over-ranks wall time, in Mray/s.  A ray = one hitBVH query.
 roofline: k_trace's algorithmic bytes (40 B per node record needed + 36 B per
         triangle tested) / k_trace time measured with HIP events
-        on its own stream (jade_stats.trace_ms), against 8 TB/s HBM.
+        on its own stream (jade_stats.trace_ms), against 8 TB/s HBM.  The bytes are
+        algorithmic: the scene is L2-resident, `traffic` (HBM bytes per launch from
+        profiles/hbm_traffic.json, PMC) is what HBM really moves.
 cpu_baseline: the CPU oracle ("port": the reference has no CPU integrator) on a
         bounded sample of the same scene, rank 0 at N = 1 only.
 """
@@ -190,6 +192,9 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes / launches, "avg_launch_ms": st.trace_ms / launches,
                 "launches": launches, "trace_share_of_step_time": trace_s / (st.kernel_ms * 1e-3) if st.kernel_ms else None,
+                "note": "achieved counts the reference traversal's ALGORITHMIC bytes (SURVEY.md 8d); the scene is L2-resident, so "
+                        "traffic (HBM bytes per launch, PMC) is ~10x smaller and frac may exceed 1; PMC shows k_trace bound by VALU "
+                        "issue (profiles/r01_v5_sq_summary.json, DESIGN.md 3.4)",
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -64,10 +64,13 @@ def test_degenerate_rays(oracle, hip):
     with oracle.scene(hs) as so, hip.scene(hs) as sh:
         i_o, t_o, p_o, st_o = so.trace_rays(o, d, skip)
         i_h, t_h, p_h, st_h = sh.trace_rays(o, d, skip)
+        # any negative skip index means "no source triangle" (-2 is the device's own camera-ray marker)
+        i_n, t_n, p_n, st_n = sh.trace_rays(o, d, np.full(len(o), -2, np.int32))
     assert np.array_equal(i_o, i_h)
     assert (st_o.nodes_visited, st_o.tris_tested) == (st_h.nodes_visited, st_h.tris_tested)
     hit = i_o >= 0
     assert np.array_equal(p_o[hit].view(np.uint32), p_h[hit].view(np.uint32))
+    assert np.array_equal(i_n, i_h) and np.array_equal(p_n[hit].view(np.uint32), p_h[hit].view(np.uint32))
 
 
 def test_extreme_image_shapes(oracle, hip):
