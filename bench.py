@@ -173,7 +173,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.config}: jade statue stand-in (69,634 triangles, SAH BVH), {width}x{height}, "
+                "workload": f"{args.config}: jade statue stand-in ({hs.n_triangles:,} triangles, {args.bvh.upper()} BVH), {width}x{height}, "
                             f"{spp_step} spp per step, tiles dealt over {world} GPU(s)",
                 "spp_per_step": spp_step, "width": width, "height": height, "triangles": hs.n_triangles,
                 "bvh_nodes": hs.n_nodes, "bvh_depth": hs.bvh_depth, "parallelism": f"tiles{world}",

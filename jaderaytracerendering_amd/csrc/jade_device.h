@@ -148,6 +148,14 @@ struct DevCounters {
 #define JADE_REFILL_MIN 32 /* idle lanes in a wave that trigger write-back + refill (8: 343, 16: 331, 32: 313, 48: 316 ms of k_trace per 256-spp step) */
 #endif
 
+// The per-(pixel, lane) partial sums: 3 planes of JADE_SAMPLE_LANES * npx floats — a full 4K frame on
+// one GPU is 3 x 2.1 G entries, past what an int index reaches, so these take 64-bit plane sizes.
+static __device__ __forceinline__ jvec3 ld3w(const float* a, size_t plane, size_t i) { return jv(a[i], a[plane + i], a[2 * plane + i]); }
+static __device__ __forceinline__ void st3w(float* a, size_t plane, size_t i, jvec3 v) {
+  a[i] = v.x;
+  a[plane + i] = v.y;
+  a[2 * plane + i] = v.z;
+}
 static __device__ __forceinline__ jvec3 ld3(const float* a, int npix, int p) {
   return jv(a[p], a[npix + p], a[2 * npix + p]);
 }

@@ -231,9 +231,9 @@ static __device__ __forceinline__ void shade_record(const DevScene& S, const Pat
         // this sample's (pixel, lane): only this record touches it in this block
         {
           const NextSample cs = next_sample(P, p, done);  // the sample that just ended
-          const int si = (int)((cs.sidx % JADE_SAMPLE_LANES) * (uint32_t)P.npx) + cs.pixel;
-          const int sn = JADE_SAMPLE_LANES * P.npx;
-          st3(P.sum, sn, si, jv_add(ld3(P.sum, sn, si), color));
+          const size_t si = (size_t)(cs.sidx % JADE_SAMPLE_LANES) * (size_t)P.npx + (size_t)cs.pixel;
+          const size_t sn = (size_t)JADE_SAMPLE_LANES * (size_t)P.npx;
+          st3w(P.sum, sn, si, jv_add(ld3w(P.sum, sn, si), color));
         }
         done += 1;
         c.c_samples += 1;
@@ -533,9 +533,9 @@ __global__ void k_resolve(PathState P, RenderConst R, const int32_t* tile_ids, f
   jvec3 m = jv(0, 0, 0);
   if (valid) {
     // add the JADE_SAMPLE_LANES partial sums in lane order (jade_rt.h)
-    const int sn = JADE_SAMPLE_LANES * P.npx;
-    jvec3 s = ld3(P.sum, sn, p);
-    for (int l = 1; l < JADE_SAMPLE_LANES; ++l) s = jv_add(s, ld3(P.sum, sn, l * P.npx + p));
+    const size_t sn = (size_t)JADE_SAMPLE_LANES * (size_t)P.npx;
+    jvec3 s = ld3w(P.sum, sn, (size_t)p);
+    for (int l = 1; l < JADE_SAMPLE_LANES; ++l) s = jv_add(s, ld3w(P.sum, sn, (size_t)l * (size_t)P.npx + (size_t)p));
     m = jv(s.x * inv_spp, s.y * inv_spp, s.z * inv_spp);
   }
   if (out_rgb) {

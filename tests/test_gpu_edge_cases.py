@@ -87,6 +87,31 @@ def test_extreme_image_shapes(oracle, hip):
     assert st.samples == 0 and st.rays_primary == 0 and (rgb == 0).all()
 
 
+def test_4k_frame_on_one_gpu(hip):
+    """3840x2160 on ONE GPU (BASELINE.json's C5 frame size): the per-(pixel, lane) sum planes hold
+    3 x 2.1 G floats, past a 32-bit index.  Two half-frame renders (whose planes are half as long)
+    must add up to the full-frame render bit for bit, and every sample must be accounted for."""
+    hs, cfg = config_scene("C2")
+    w, h = 3840, 2160
+    p = B.params_from_config(cfg, spp=1)
+    p.width, p.height = w, h
+    with hip.scene(hs) as sc:
+        full, full_b, st_full = sc.render(p)
+        acc = np.zeros_like(full)
+        tot = {k: 0 for k in counters(st_full)}
+        for r in range(2):
+            q = B.params_from_config(cfg, spp=1, tile_rank=r, tile_nranks=2)
+            q.width, q.height = w, h
+            part, _, st = sc.render(q)
+            acc += part
+            for k, v in counters(st).items():
+                tot[k] += v
+    assert st_full.samples == w * h and st_full.rays_primary == w * h
+    assert np.isfinite(full).all()
+    assert np.array_equal(acc.view(np.uint32), full.view(np.uint32))
+    assert tot == counters(st_full)
+
+
 def test_empty_and_invalid_calls(hip):
     hs, cfg = config_scene("tiny")
     with hip.scene(hs) as sh:
