@@ -34,7 +34,7 @@ extern "C" {
 
 /* bump whenever a struct layout or a documented semantic changes; callers compare
  * jade_abi_version() with the value they were compiled against */
-#define JADE_ABI_VERSION 2
+#define JADE_ABI_VERSION 3
 
 /* status codes */
 #define JADE_OK 0
@@ -67,8 +67,11 @@ extern "C" {
  * partial sums (sample s goes to lane s % JADE_SAMPLE_LANES, in increasing s)
  * which are added in lane order at resolve time: the result does not depend
  * on how samples are batched into steps, on the tile partition, or on how
- * many of a pixel's samples a backend keeps in flight at once. */
-#define JADE_SAMPLE_LANES 256
+ * many of a pixel's samples a backend keeps in flight at once.  The lane
+ * count is also the most samples of one pixel that can be in flight at once:
+ * 1024 lets a GPU that holds an eighth of a 1080p frame (8-GPU tiling) keep as
+ * many paths in flight as one that holds the whole frame. */
+#define JADE_SAMPLE_LANES 1024
 
 /* == Triangle_cu, PathTrace.cu:327-338 (112 bytes). */
 typedef struct jade_triangle {

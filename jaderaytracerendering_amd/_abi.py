@@ -6,7 +6,8 @@ reference device structs, PathTrace.cu:327-351).
 """
 import ctypes as C
 
-JADE_ABI_VERSION = 2
+JADE_ABI_VERSION = 3
+JADE_SAMPLE_LANES = 1024
 JADE_OK, JADE_ERR_INVALID, JADE_ERR_DEVICE, JADE_ERR_NOMEM, JADE_ERR_UNSUPPORTED = range(5)
 DIFFUSE, MIRROR = 0, 1
 NO_REFRACT, SUB_SURFACE, DIR_REFRACT = 0, 1, 2

@@ -45,7 +45,8 @@
 /* leaf cursors waiting for their triangle tests, same LDS column (power of two) */
 #define JADE_LDS_STATE 8  /* ray-state words, same column (jade_trace.h): 20 words * 256 lanes = 20 KB/block, 8 blocks/CU */
 #define JADE_TRACE_BLOCK 256
-#define JADE_RECORD_BUDGET (72ll << 20) /* path records kept in flight per GPU (~250 B each) */
+#define JADE_RECORD_MEMORY 0.55 /* share of the free device memory that path records + partial sums may take: paths in \
+                                  flight are what fills the wide passes (1080p on one GPU: 32 -> 256 records per pixel = +21 %) */
 
 struct DevScene {
   const float4* nodes;        // 4 x float4 per internal node

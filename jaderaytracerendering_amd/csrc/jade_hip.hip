@@ -408,7 +408,7 @@ __global__ __launch_bounds__(JADE_SHADE_BLOCK) void k_shade_lean(DevScene S, Pat
 }
 
 #ifndef JADE_STEPS_PER_PICK
-#define JADE_STEPS_PER_PICK 3 /* units of the picked kind per wave iteration (1: 313, 2: 306, 3: 303, 4: 301 ms with REFILL_MIN 32) */
+#define JADE_STEPS_PER_PICK 4 /* units of the picked kind per wave iteration (k_trace per 256-spp step, packed build: 2: 282, 3: 275, 4: 273 ms) */
 #endif
 #ifndef JADE_COST_NODE
 #define JADE_COST_NODE 100 /* instructions issued by a node-walk iteration ... */
@@ -854,16 +854,31 @@ int jade_render_begin(jade_scene* s, const jade_render_params* rp) {
       if ((x + y) % rp->tile_nranks == rp->tile_rank) s->tile_ids.push_back(y * tx + x);
   const int nslots = s->n_emit + 2;
   const int64_t npx64 = (int64_t)s->tile_ids.size() * 256;
-  // records per pixel: keep about JADE_RECORD_BUDGET paths in flight whatever the image share
+  // Records per pixel: as many paths in flight as JADE_RECORD_MEMORY of the free device memory holds (the
+  // partial sums come out of the same share), whatever the image share of this GPU: more records = fewer,
+  // wider passes.  288 GB is what makes 530 M paths (112 GB) for a full 1080p frame affordable.
+  const double bytes_per_record = 4.0 * (29 + 8 * nslots);  // PathState + queue entry + two list entries
+  const double sums_bytes = 12.0 * JADE_SAMPLE_LANES * (double)npx64;
+  size_t mem_free = 0, mem_total = 0;
+  HIP_TRY(hipMemGetInfo(&mem_free, &mem_total));
+  mem_free += s->b_state.bytes + s->b_queue.bytes + s->b_active[0].bytes + s->b_active[1].bytes;  // ours to reuse
+  const double budget = JADE_RECORD_MEMORY * (double)mem_free - sums_bytes;
   int rpp = JADE_SAMPLE_LANES;
-  while (rpp > 1 && npx64 * rpp > JADE_RECORD_BUDGET) rpp >>= 1;
+  while (rpp > 1 && ((double)npx64 * rpp * bytes_per_record > budget || npx64 * rpp * nslots >= ((int64_t)1 << 32) ||
+                     npx64 * rpp >= ((int64_t)1 << 31)))
+    rpp >>= 1;
   if (const char* e = getenv("JADE_RECORDS_PER_PIXEL")) {  // test hook: results must not depend on it
     int v = atoi(e);
     if (v >= 1 && v <= JADE_SAMPLE_LANES && (v & (v - 1)) == 0) rpp = v;
   }
   const int64_t npix64 = npx64 * rpp;
-  if (npix64 * nslots >= ((int64_t)1 << 32) || npix64 >= ((int64_t)1 << 31) || npx64 * JADE_SAMPLE_LANES >= ((int64_t)1 << 31))
+  if (npix64 * nslots >= ((int64_t)1 << 32) || npix64 >= ((int64_t)1 << 31))
     return fail(JADE_ERR_UNSUPPORTED, "pixels x records x (emitters + 2) exceeds the 32-bit ray-slot index");
+  if (sums_bytes + (double)npix64 * bytes_per_record > 0.95 * (double)mem_free)
+    return fail(JADE_ERR_NOMEM, "frame does not fit the device memory (partial sums + one record per pixel)");
+  if (getenv("JADE_LOG_PASSES"))
+    fprintf(stderr, "[jade] %lld pixels x %d records, %.1f GB of path state + %.1f GB of partial sums (%.0f GB free)\n", (long long)npx64,
+            rpp, npix64 * bytes_per_record / 1e9, sums_bytes / 1e9, mem_free / 1e9);
   s->have_rp = false;
   s->rp = *rp;
   RenderConst& R = s->rc;

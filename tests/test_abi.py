@@ -109,5 +109,6 @@ def test_abi_version_is_single_sourced():
     text = open(os.path.join(ROOT, "include", "jade_rt.h")).read()
     ver = int(re.search(r"#define JADE_ABI_VERSION (\d+)", text).group(1))
     assert ver == _abi.JADE_ABI_VERSION
+    assert int(re.search(r"#define JADE_SAMPLE_LANES (\d+)", text).group(1)) == _abi.JADE_SAMPLE_LANES
     for path in (B.HIP_LIB, os.path.join(ROOT, "oracle", "libjade_oracle.so")):
         assert ctypes.CDLL(path).jade_abi_version() == ver, path

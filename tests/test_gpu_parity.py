@@ -14,6 +14,7 @@ import numpy as np
 import pytest
 
 from conftest import B, J, config_scene, counters, rel_l2
+from jaderaytracerendering_amd import _abi
 
 pytestmark = pytest.mark.gpu
 
@@ -129,13 +130,13 @@ def test_progressive_equals_single_call(hip):
 
 
 def test_result_independent_of_paths_in_flight(hip, monkeypatch):
-    """The backend picks how many records per pixel work on a pixel's 256 sample lanes
-    (32 for a full frame, 256 for an eighth of it): the image must not depend on it."""
+    """The backend picks how many records per pixel work on a pixel's JADE_SAMPLE_LANES sample lanes
+    (256 for a full 1080p frame on one GPU, 1024 for an eighth of it): the image must not depend on it."""
     hs, cfg = config_scene("tinyjade")
     p = B.params_from_config(cfg, spp=40)
     p.width, p.height = 24, 20
     ref = None
-    for rpp in ("1", "8", "256"):
+    for rpp in ("1", "8", "256", "1024"):
         monkeypatch.setenv("JADE_RECORDS_PER_PIXEL", rpp)
         with hip.scene(hs) as sc:
             rgb, bgr, st = sc.render(p)
@@ -169,7 +170,7 @@ def test_result_independent_of_shade_schedule(hip, monkeypatch):
 def test_many_samples_per_lane_match_oracle(oracle, hip):
     """spp > JADE_SAMPLE_LANES: several samples per lane, summed in lane order by both backends."""
     hs, cfg = config_scene("tiny")
-    p = B.params_from_config(cfg, spp=300)
+    p = B.params_from_config(cfg, spp=_abi.JADE_SAMPLE_LANES * 2 + 44)
     p.width, p.height = 12, 10
     _assert_parity(*_render_both(oracle, hip, hs, p))
 
@@ -202,7 +203,6 @@ def test_stack_spill_path(oracle):
 
 def test_preview_tone_operator(oracle, hip):
     """jade_render_resolve_ex with the GL preview's operator (pass3.fsh:8-18 == PathTrace.cu:669-672)."""
-    from jaderaytracerendering_amd import _abi
     hs, cfg = config_scene("tinyjade")
     p = B.params_from_config(cfg, spp=8)
     with oracle.scene(hs) as so, hip.scene(hs) as sh:
