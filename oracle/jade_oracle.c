@@ -1041,10 +1041,14 @@ int jade_render_resolve_ex(jade_scene* s, int tonemap, float limit, float* out_r
       size_t pi = (size_t)y * rp->width + x;
       const size_t np = (size_t)rp->width * rp->height;
       jvec3 tot = jv(s->sum[3 * pi], s->sum[3 * pi + 1], s->sum[3 * pi + 2]);
-      for (size_t l = 1; l < JADE_SAMPLE_LANES; ++l) {
+      /* lanes >= spp_done were never written: they are +0.0, and adding +0.0 any number of times is
+       * adding it once (it only turns a -0.0 total into +0.0) - the untouched pages stay unmapped */
+      const size_t used = s->spp_done < JADE_SAMPLE_LANES ? (size_t)s->spp_done : (size_t)JADE_SAMPLE_LANES;
+      for (size_t l = 1; l < used; ++l) {
         const float* q = s->sum + 3 * (l * np + pi);
         tot = jv_add(tot, jv(q[0], q[1], q[2]));
       }
+      if (used < JADE_SAMPLE_LANES) tot = jv_add(tot, jv(0.0f, 0.0f, 0.0f));
       jvec3 m = jv(tot.x * inv, tot.y * inv, tot.z * inv);
       if (out_rgb) { out_rgb[3 * pi] = m.x; out_rgb[3 * pi + 1] = m.y; out_rgb[3 * pi + 2] = m.z; }
       if (out_bgr8) tonemap_pack(m, tonemap, limit, out_bgr8 + 3 * pi);
