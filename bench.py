@@ -194,7 +194,7 @@ def main():
                 "launches": launches, "trace_share_of_step_time": trace_s / (st.kernel_ms * 1e-3) if st.kernel_ms else None,
                 "note": "achieved counts the reference traversal's ALGORITHMIC bytes (SURVEY.md 8d); the scene is L2-resident, so "
                         "traffic (HBM bytes per launch, PMC) is ~10x smaller and frac may exceed 1; PMC shows k_trace bound by VALU "
-                        "issue (profiles/r01_v5_sq_summary.json, DESIGN.md 3.4)",
+                        "issue (profiles/r01_v6_sq_summary.json, DESIGN.md 3.4)",
             },
         }
         if world == 1 and not args.no_cpu_baseline:
