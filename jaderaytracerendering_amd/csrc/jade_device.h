@@ -45,7 +45,7 @@
 /* leaf cursors waiting for their triangle tests, same LDS column (power of two) */
 #define JADE_LDS_STATE 8  /* ray-state words, same column (jade_trace.h): 20 words * 256 lanes = 20 KB/block, 8 blocks/CU */
 #define JADE_TRACE_BLOCK 256
-#define JADE_RECORD_MEMORY 0.55 /* share of the free device memory that path records + partial sums may take: paths in \
+#define JADE_RECORD_MEMORY 0.60 /* share of the free device memory that path records + partial sums may take: paths in \
                                   flight are what fills the wide passes (1080p on one GPU: 32 -> 256 records per pixel = +21 %) */
 
 struct DevScene {
