@@ -67,9 +67,10 @@ struct DevScene {
 // the samples s = m, m + rpp, m + 2 rpp, ... of owned pixel `pixel`
 // (pixel = owned_tile * 256 + ly * 16 + lx), one after the other, so a rank
 // has npix = npx * rpp paths in flight.  rpp (records per pixel, a power of two
-// <= JADE_SAMPLE_LANES) is chosen per render so that npix stays about constant:
-// 32 for a full 1080p frame on one GPU, 256 for an eighth of it - the same
-// number of paths in flight per GPU whatever the tile partition.  Sample s adds
+// <= JADE_SAMPLE_LANES) is sized per render from the free device memory
+// (JADE_RECORD_MEMORY): 256 for a full 1080p frame on one GPU, 1024 for an
+// eighth of it - hundreds of millions of paths in flight per GPU whatever the
+// tile partition.  Sample s adds
 // into partial sum s % JADE_SAMPLE_LANES of its pixel, which only record
 // s % rpp ever touches, in increasing s: no atomics, and a result that does
 // not depend on rpp.  `nslots` = n_emit + 2 ray slots per record: [0, n_emit)
