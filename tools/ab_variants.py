@@ -10,6 +10,8 @@ sys.path.insert(0, ROOT)
 import jaderaytracerendering_amd as J  # noqa: E402
 from jaderaytracerendering_amd import _abi, backend as B  # noqa: E402
 
+# every variant holds its own path state: cap the records so that several fit the device side by side
+os.environ.setdefault("JADE_RECORDS_PER_PIXEL", "32")
 hs, cfg = J.build_config("C3")
 scenes = {}
 for name in sys.argv[1:]:
