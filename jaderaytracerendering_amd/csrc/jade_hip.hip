@@ -407,6 +407,9 @@ __global__ __launch_bounds__(JADE_SHADE_BLOCK) void k_shade_lean(DevScene S, Pat
   shade_tail<true>(P, p, st, c, defer, nullptr, heavy_out, queue, qc, ctr);
 }
 
+#ifndef JADE_TRACE_PROFILE
+#define JADE_TRACE_PROFILE 0
+#endif
 #ifndef JADE_STEPS_PER_PICK
 #define JADE_STEPS_PER_PICK 4 /* units of the picked kind per wave iteration (k_trace per 256-spp step, packed build: 2: 282, 3: 275, 4: 273 ms) */
 #endif
@@ -432,6 +435,9 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
   const int npix = P.npix;
   const size_t plane = (size_t)P.nslots * npix;
   uint32_t V = 0, T = 0;  // wave totals (uniform: they live in SGPRs)
+#if JADE_TRACE_PROFILE
+  uint32_t prof_units = 0, prof_lanes = 0;  // development: units run of one kind (1 node, 2 triangle, 3 any) and lanes that took part
+#endif
   // wave-local chunk of the queue: [lbase, lend) (wave-uniform)
   uint32_t lbase = 0, lend = 0;
   bool queue_empty = false;
@@ -498,17 +504,31 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
 #pragma nounroll
         for (int rep = 0; rep < JADE_STEPS_PER_PICK; ++rep) {
           bool c1 = false, c2 = false;
-          if (active && ray_can_walk(r)) ray_step_node(r, S, stk, &c1, &c2);
+          const bool go = active && ray_can_walk(r);
+#if JADE_TRACE_PROFILE == 1
+          prof_units += 1;
+          prof_lanes += (uint32_t)__popcll(__ballot(go));
+#endif
+          if (go) ray_step_node(r, S, stk, &c1, &c2);
           V += (uint32_t)__popcll(__ballot(c1)) + (uint32_t)__popcll(__ballot(c2));
         }
       } else {
 #pragma nounroll
         for (int rep = 0; rep < JADE_STEPS_PER_PICK; ++rep) {
           bool tested = false;
-          if (active && ray_can_test(r)) ray_step_tri(r, S, stk, &tested);
+          const bool go = active && ray_can_test(r);
+#if JADE_TRACE_PROFILE == 2
+          prof_units += 1;
+          prof_lanes += (uint32_t)__popcll(__ballot(go));
+#endif
+          if (go) ray_step_tri(r, S, stk, &tested);
           T += (uint32_t)__popcll(__ballot(tested));
         }
       }
+#if JADE_TRACE_PROFILE == 3
+      prof_units += 1;
+      prof_lanes += (uint32_t)__popcll(__ballot(active));
+#endif
     }
     const bool fin = active && ray_done(r);
     if (fin) {
@@ -518,6 +538,10 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
   }
   if (lane == 0) {
     DevCounters* cs = ctr + (blockIdx.x % JADE_CTR_SHARDS);
+#if JADE_TRACE_PROFILE
+    atomicAdd(&cs->pad[0], (unsigned long long)prof_units);
+    atomicAdd(&cs->pad[1], (unsigned long long)prof_lanes);
+#endif
     if (V) atomicAdd(&cs->nodes_visited, (unsigned long long)V);
     if (T) atomicAdd(&cs->tris_tested, (unsigned long long)T);
   }
@@ -920,7 +944,12 @@ static hipError_t sum_counters(jade_scene* s, DevCounters* out) {
     out->rays_primary += c.rays_primary; out->rays_secondary += c.rays_secondary;
     out->nodes_visited += c.nodes_visited; out->tris_tested += c.tris_tested;
     out->shaded_hits += c.shaded_hits; out->samples += c.samples;
+    out->pad[0] += c.pad[0]; out->pad[1] += c.pad[1];
   }
+#if JADE_TRACE_PROFILE
+  fprintf(stderr, "[jade] k_trace profile %d: %llu units, %.1f lanes per unit\n", JADE_TRACE_PROFILE, out->pad[0],
+          out->pad[0] ? (double)out->pad[1] / (double)out->pad[0] : 0.0);
+#endif
   return e;
 }
 
