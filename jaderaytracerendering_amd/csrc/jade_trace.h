@@ -321,12 +321,17 @@ static __device__ __forceinline__ void ray_step_tri(RayState& r, const DevScene&
 // near-first descent (PathTrace.cu:835-848), the far child pushed.  *c1, *c2: the child exists (its
 // record counts as visited).
 static __device__ __forceinline__ void ray_step_node(RayState& r, const DevScene& S, const LdsStack& stk, bool* c1, bool* c2) {
-  if (r.cur & JADE_REF_LEAF) {  // a leaf left over from a step that found the FIFO full (room was checked by ray_can_walk)
-    leaf_queue(r, stk, r.cur);
-    r.cur = walk_pop(r, stk);
-  }
-  if (r.cur != JADE_REF_NONE && !(r.cur & JADE_REF_LEAF)) {
-    const float4* nd = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.nodes) + r.cur * 64u);
+  // One queue site and one pop site for every way a step can need them (a leaf left over from a step
+  // that found the FIFO full, the near child being a leaf, the only entered child being a leaf, no child
+  // entered): code that exists once runs once per step, for all the lanes that need it together.
+  uint32_t cur = r.cur;
+  uint32_t leafv = 0;     // leaf met by this step (queued below)
+  bool need_pop = false;  // the walk continues from the stack
+  if (cur & JADE_REF_LEAF) {  // left over (room was checked by ray_can_walk)
+    leafv = cur;
+    need_pop = true;
+  } else {
+    const float4* nd = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.nodes) + cur * 64u);
     const float4 a = nd[0], b = nd[1], c = nd[2];
     const uint2 rf = *reinterpret_cast<const uint2*>(nd + 3);
     const jvec3 inv = jv(lds_getf(stk, LW_INVX), lds_getf(stk, LW_INVY), lds_getf(stk, LW_INVZ));
@@ -347,21 +352,29 @@ static __device__ __forceinline__ void ray_step_node(RayState& r, const DevScene
     if (!*c1) d1 = -1.0f;
     if (!*c2) d2 = -1.0f;
     const bool in1 = d1 > 0, in2 = d2 > 0;
-    if (in1 && in2) {
+    const bool room = leaf_room(r);
+    if (in1 && in2) {  // near child first (d1 < d2, PathTrace.cu:835-848)
       const bool first = d1 < d2;
-      stack_push(stk, (int)RS_SP(r), first ? rf.y : rf.x);  // the far child
-      r.ctl += 1u;
-      r.cur = first ? rf.x : rf.y;
+      const uint32_t near = first ? rf.x : rf.y, far = first ? rf.y : rf.x;
+      if ((near & JADE_REF_LEAF) && room) {  // the near leaf is met now; the far child is next, nothing to push
+        leafv = near;
+        cur = far;
+      } else {
+        stack_push(stk, (int)RS_SP(r), far);
+        r.ctl += 1u;
+        cur = near;
+      }
     } else if (in1 || in2) {
-      r.cur = in1 ? rf.x : rf.y;
+      cur = in1 ? rf.x : rf.y;
+      if ((cur & JADE_REF_LEAF) && room) {
+        leafv = cur;
+        need_pop = true;
+      }
     } else {
-      r.cur = walk_pop(r, stk);
+      need_pop = true;
     }
   }
-  // a leaf met by this step is queued at once (it is not worth an iteration of its own);
-  // one that does not fit stays in `cur` until triangle tests have made room
-  if ((r.cur & JADE_REF_LEAF) && leaf_room(r)) {
-    leaf_queue(r, stk, r.cur);
-    r.cur = walk_pop(r, stk);
-  }
+  if (leafv) leaf_queue(r, stk, leafv);
+  if (need_pop) cur = walk_pop(r, stk);
+  r.cur = cur;  // may be a leaf (the far child, a popped one, or one that found no room): the next step queues it
 }
