@@ -114,11 +114,13 @@ def main():
     scene.begin(params)
     for _ in range(args.warmup):
         scene.step(spp_step)
+    scene.flush()  # the warm-up's last paths finish outside the timed region ...
     st = _abi.Stats()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        scene.step(spp_step, st)  # synchronous: returns when the step's kernels are done
+        scene.step(spp_step, st)  # synchronous; a step may hand its last few paths to the next one (jade_rt.h)
+    scene.flush(st)  # ... and the timed steps' own inside it: every sample of the K steps is done before the clock stops
     barrier()
     dt = time.perf_counter() - t0
 

@@ -187,6 +187,14 @@ int jade_render(jade_scene* scene, const jade_render_params* params, float* out_
 int jade_render_begin(jade_scene* scene, const jade_render_params* params);
 int jade_render_step(jade_scene* scene, int32_t spp, jade_stats* stats_accum);
 int jade_render_resolve(jade_scene* scene, float* out_rgb, uint8_t* out_bgr8);
+/* A backend may return from step() while the last, longest paths of that step
+ * are still unfinished and carry them into the next step (samples are
+ * independent work items, so the result is the same; what it saves is the
+ * nearly empty passes at the end of every step).  flush() finishes them: after
+ * it every sample requested so far is in the sums and in stats_accum.  Every
+ * resolve variant flushes first; a caller only needs flush() to close a timed
+ * region or to read final statistics without resolving. */
+int jade_render_flush(jade_scene* scene, jade_stats* stats_accum);
 
 /* Resolve with a choice of tone operator for out_bgr8 (out_rgb is always the
  * linear mean):

@@ -104,6 +104,7 @@ RT_SYMBOLS = {
                                     C.POINTER(Stats)]),
     "jade_render_begin": (C.c_int, [C.c_void_p, C.POINTER(RenderParams)]),
     "jade_render_step": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(Stats)]),
+    "jade_render_flush": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "jade_render_resolve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "jade_render_resolve_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "jade_render_resolve_tiles_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -110,6 +110,12 @@ class Scene:
         self.backend.check(self.backend.lib.jade_render_step(self._h, int(spp), C.byref(st)))
         return st
 
+    def flush(self, stats=None):
+        """Finish the paths a step may have carried over (jade_rt.h); resolve() does it implicitly."""
+        st = stats if stats is not None else _abi.Stats()
+        self.backend.check(self.backend.lib.jade_render_flush(self._h, C.byref(st)))
+        return st
+
     def resolve(self, want_rgb=True, want_bgr8=True, tonemap=None, limit=1.5):
         """tonemap None/ACES: PathTrace.cu:680-682; _abi.TONEMAP_REINHARD: the preview's pass3.fsh operator."""
         h, w = self._params.height, self._params.width

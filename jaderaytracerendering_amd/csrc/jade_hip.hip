@@ -121,6 +121,9 @@ __global__ __launch_bounds__(JADE_ARM_BLOCK) void k_arm(PathState P, uint32_t ta
   }
 }
 
+#ifndef JADE_CARRY_RECORDS
+#define JADE_CARRY_RECORDS 32768u /* a step hands its last paths to the next one once fewer than this (and < 0.1 % of its records) are active */
+#endif
 #ifndef JADE_SHADE_BLOCK
 #define JADE_SHADE_BLOCK 512 /* threads per k_shade block: one queue + one list atomic per block (512: +1.8 % over 256; 1024: none) */
 #endif
@@ -641,6 +644,7 @@ struct jade_scene {
   std::vector<int32_t> tile_ids;
   int trace_blocks = 0;
   int64_t spp_done = 0;
+  bool tail_pending = false;  // the last step left its longest paths unfinished (jade_render_flush)
   ~jade_scene() {
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -913,6 +917,7 @@ int jade_render_begin(jade_scene* s, const jade_render_params* rp) {
   R.two_over_h = 2.0 / (double)rp->height;
   R.aspect = (double)rp->width / (double)rp->height;
   s->spp_done = 0;
+  s->tail_pending = false;
   if (npix64 == 0) { s->ps.npix = 0; s->ps.npx = 0; s->have_rp = true; return JADE_OK; }
   int rc = setup_state(s, (int)npx64, rpp, nslots);
   if (rc) return rc;
@@ -956,7 +961,7 @@ static hipError_t sum_counters(jade_scene* s, DevCounters* out) {
 // shade/trace passes until a shade pass emits no ray.  The host reads the
 // queue length after every shade pass (that sync is also what lets one event
 // pair time every k_trace launch on this stream).
-static int run_passes(jade_scene* s, uint32_t target_spp, double* ms_out, double* trace_ms_out, uint64_t* launches_out) {
+static int run_passes(jade_scene* s, uint32_t target_spp, bool may_carry, double* ms_out, double* trace_ms_out, uint64_t* launches_out) {
   const int npix = s->ps.npix;
   QueueCtl* qc = s->b_ctl.as<QueueCtl>();
   hipEvent_t ev0, ev1, ta, tb;
@@ -965,9 +970,10 @@ static int run_passes(jade_scene* s, uint32_t target_spp, double* ms_out, double
   HIP_TRY(hipEventCreate(&ta));
   HIP_TRY(hipEventCreate(&tb));
   HIP_TRY(hipEventRecord(ev0, s->stream));
-  bool trace_pending = false;
+  bool trace_pending = false, carried = false;
   double trace_ms = 0;
   uint64_t launches = 0;
+  s->tail_pending = false;  // whatever an earlier step left is part of this call's work
   // the records with work in this step
   uint32_t host_ctl[3] = {0, 0, 0};
   HIP_TRY(hipMemsetAsync(qc, 0, 12, s->stream));
@@ -976,6 +982,7 @@ static int run_passes(jade_scene* s, uint32_t target_spp, double* ms_out, double
   HIP_TRY(hipMemcpyAsync(host_ctl, qc, 12, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
   uint32_t n_active = host_ctl[1];
+  const uint32_t n_armed = n_active;  // records with work at the start of this call
   int cur = 0, pass_no = 0;
   const bool log_passes = getenv("JADE_LOG_PASSES") != nullptr;
   // While at least a quarter of the records are active, a pass is k_shade_lean over all records
@@ -1042,6 +1049,12 @@ static int run_passes(jade_scene* s, uint32_t target_spp, double* ms_out, double
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(tb, s->stream));
     trace_pending = true;
+    if (may_carry && n_active < JADE_CARRY_RECORDS && (uint64_t)n_active * 1024 < (uint64_t)n_armed) {
+      // The few long paths left would take dozens of nearly empty passes: leave them suspended (their
+      // rays are traced, their hits wait to be folded in) for the next step's first pass, or for flush.
+      s->tail_pending = true;
+      carried = true;
+    }
     if (log_passes) {
       HIP_TRY(hipEventSynchronize(tb));
       float t = 0;
@@ -1050,6 +1063,15 @@ static int run_passes(jade_scene* s, uint32_t target_spp, double* ms_out, double
               n_active, host_ctl[0], shade_ms, lean_ms, t, host_ctl[0] / (t * 1e3));
     }
     ++pass_no;
+    if (carried) break;
+  }
+  if (trace_pending) {  // the launch timed by (ta, tb) when the loop stopped right after it
+    HIP_TRY(hipEventSynchronize(tb));
+    float t = 0;
+    HIP_TRY(hipEventElapsedTime(&t, ta, tb));
+    trace_ms += t;
+    launches += 1;
+    trace_pending = false;
   }
   HIP_TRY(hipEventRecord(ev1, s->stream));
   HIP_TRY(hipEventSynchronize(ev1));
@@ -1065,26 +1087,23 @@ static int run_passes(jade_scene* s, uint32_t target_spp, double* ms_out, double
   return JADE_OK;
 }
 
-int jade_render_step(jade_scene* s, int32_t spp, jade_stats* st) {
-  if (!s || !s->have_rp) return fail(JADE_ERR_INVALID, "jade_render_begin not called");
-  if (spp < 0) return fail(JADE_ERR_INVALID, "negative spp");
-  HIP_TRY(hipSetDevice(s->device));
-  s->spp_done += spp;
-  if (s->ps.npix == 0 || spp == 0) return JADE_OK;
+// runs the passes for every sample up to spp_done; may_carry: the last paths may be left for later
+static int advance(jade_scene* s, int64_t from0, bool may_carry, jade_stats* st) {
   HIP_TRY(hipMemsetAsync(s->b_ctr.p, 0, sizeof(DevCounters) * JADE_CTR_SHARDS, s->stream));
   double ms = 0, trace_ms = 0;
   uint64_t launches = 0;
-  // one block of JADE_SAMPLE_LANES samples at a time (see PathState): records may not run
-  // ahead into the next block while another record still owns a (pixel, lane) sum of this one
-  for (int64_t from = s->spp_done - spp; from < s->spp_done;) {
+  // pixel rotation only: one block of JADE_SAMPLE_LANES samples at a time (see PathState): records may not
+  // run ahead into the next block while another record still owns a (pixel, lane) sum of this one
+  for (int64_t from = from0;;) {
     int64_t to = (from / JADE_SAMPLE_LANES + 1) * JADE_SAMPLE_LANES;
     if (to > s->spp_done || s->ps.stride == 0) to = s->spp_done;  // no rotation: no block barrier needed
     double m1 = 0, t1 = 0;
     uint64_t l1 = 0;
-    int rc = run_passes(s, (uint32_t)to, &m1, &t1, &l1);
+    int rc = run_passes(s, (uint32_t)to, may_carry && s->ps.stride == 0, &m1, &t1, &l1);
     if (rc) return rc;
     ms += m1; trace_ms += t1; launches += l1;
     from = to;
+    if (from >= s->spp_done) break;
   }
   if (st) {
     DevCounters c{};
@@ -1100,6 +1119,23 @@ int jade_render_step(jade_scene* s, int32_t spp, jade_stats* st) {
     st->trace_launches += launches;
   }
   return JADE_OK;
+}
+
+int jade_render_step(jade_scene* s, int32_t spp, jade_stats* st) {
+  if (!s || !s->have_rp) return fail(JADE_ERR_INVALID, "jade_render_begin not called");
+  if (spp < 0) return fail(JADE_ERR_INVALID, "negative spp");
+  HIP_TRY(hipSetDevice(s->device));
+  s->spp_done += spp;
+  if (s->ps.npix == 0 || spp == 0) return JADE_OK;
+  static const bool carry = !(getenv("JADE_CARRY") && atoi(getenv("JADE_CARRY")) == 0);
+  return advance(s, s->spp_done - spp, carry, st);
+}
+
+int jade_render_flush(jade_scene* s, jade_stats* st) {
+  if (!s || !s->have_rp) return fail(JADE_ERR_INVALID, "jade_render_begin not called");
+  if (!s->tail_pending || s->ps.npix == 0) return JADE_OK;
+  HIP_TRY(hipSetDevice(s->device));
+  return advance(s, s->spp_done, false, st);
 }
 
 static int resolve_to(jade_scene* s, int tonemap, float limit, float* dev_rgb, uint8_t* dev_bgr, hipStream_t stream) {
@@ -1120,6 +1156,7 @@ int jade_render_resolve_ex(jade_scene* s, int tonemap, float limit, float* out_r
   if (tonemap != JADE_TONEMAP_ACES && tonemap != JADE_TONEMAP_REINHARD) return fail(JADE_ERR_INVALID, "unknown tone operator");
   if (s->spp_done <= 0) return fail(JADE_ERR_INVALID, "no samples rendered yet");
   HIP_TRY(hipSetDevice(s->device));
+  if (int rc = jade_render_flush(s, nullptr)) return rc;
   const int npix = s->ps.npx;
   if (npix == 0) return JADE_OK;
   if (out_rgb) HIP_TRY(s->b_out_rgb.alloc((size_t)npix * 12));
@@ -1155,6 +1192,7 @@ int jade_render_resolve_tiles_device(jade_scene* s, float* dev_tiles, void* stre
   if (!s || !s->have_rp || !dev_tiles) return fail(JADE_ERR_INVALID, "bad arguments");
   if (s->spp_done <= 0) return fail(JADE_ERR_INVALID, "no samples rendered yet");
   HIP_TRY(hipSetDevice(s->device));
+  if (int rc = jade_render_flush(s, nullptr)) return rc;
   HIP_TRY(hipStreamSynchronize(s->stream));
   return resolve_to(s, JADE_TONEMAP_ACES, 0.0f, dev_tiles, nullptr, (hipStream_t)stream);
 }
@@ -1165,6 +1203,7 @@ int jade_render(jade_scene* s, const jade_render_params* rp, float* out_rgb, uin
   int rc = jade_render_begin(s, rp);
   if (rc) return rc;
   rc = jade_render_step(s, rp->spp, st);
+  if (rc == JADE_OK) rc = jade_render_flush(s, st);  // (resolve would flush too, but without the statistics)
   if (rc) return rc;
   return jade_render_resolve(s, out_rgb, out_bgr8);
 }
@@ -1216,6 +1255,7 @@ int jade_render_multi(jade_scene* const* scenes, int ndev, const jade_render_par
     p.device_id = s->device;
     int rc = jade_render_begin(s, &p);
     if (rc == JADE_OK) rc = jade_render_step(s, p.spp, &sts[i]);
+    if (rc == JADE_OK) rc = jade_render_flush(s, &sts[i]);
     if (rc == JADE_OK && s->ps.npx > 0) {
       hipError_t e = s->b_out_rgb.alloc((size_t)s->ps.npx * 12);
       if (e != hipSuccess) rc = jade_fail(JADE_ERR_NOMEM, "tile buffer allocation failed");

@@ -1025,6 +1025,13 @@ int jade_render_step(jade_scene* s, int32_t spp, jade_stats* st) {
   return JADE_OK;
 }
 
+/* the oracle finishes every sample inside step(): nothing is ever carried over */
+int jade_render_flush(jade_scene* s, jade_stats* st) {
+  (void)st;
+  if (!s || !s->have_rp) return fail(JADE_ERR_INVALID, "jade_render_begin not called");
+  return JADE_OK;
+}
+
 int jade_render_resolve(jade_scene* s, float* out_rgb, uint8_t* out_bgr8) {
   return jade_render_resolve_ex(s, JADE_TONEMAP_ACES, 0.0f, out_rgb, out_bgr8);
 }

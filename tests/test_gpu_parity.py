@@ -129,6 +129,27 @@ def test_progressive_equals_single_call(hip):
     assert np.array_equal(one_b, prog_b)
 
 
+def test_steps_may_carry_paths_over(hip):
+    """A step may leave its last, longest paths to the next step (jade_render_flush, jade_rt.h): after
+    flush the statistics of N steps equal those of one render of N*spp, and so does the image."""
+    hs, cfg = config_scene("tinyjade")
+    p = B.params_from_config(cfg, spp=12)
+    p.width, p.height = 160, 120
+    with hip.scene(hs) as sc:
+        one, one_b, st_one = sc.render(p)
+        sc.begin(p)
+        st = _abi.Stats()
+        for _ in range(3):
+            sc.step(4, st)
+        sc.flush(st)
+        assert counters(st) == counters(st_one)
+        sc.flush(st)  # nothing left: a second flush adds nothing
+        assert counters(st) == counters(st_one)
+        prog, prog_b = sc.resolve()
+    assert np.array_equal(one.view(np.uint32), prog.view(np.uint32))
+    assert np.array_equal(one_b, prog_b)
+
+
 def test_result_independent_of_paths_in_flight(hip, monkeypatch):
     """The backend picks how many records per pixel work on a pixel's JADE_SAMPLE_LANES sample lanes
     (256 for a full 1080p frame on one GPU, 1024 for an eighth of it): the image must not depend on it."""
