@@ -112,9 +112,10 @@ def main():
         torch.cuda.synchronize()
 
     scene.begin(params)
+    st_w = _abi.Stats()
     for _ in range(args.warmup):
-        scene.step(spp_step)
-    scene.flush()  # the warm-up's last paths finish outside the timed region ...
+        scene.step(spp_step, st_w)
+    scene.flush(st_w)  # the warm-up's last paths finish outside the timed region ...
     st = _abi.Stats()
     barrier()
     t0 = time.perf_counter()
@@ -157,8 +158,8 @@ def main():
         traffic = None
         prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(prof):
-            try:
-                traffic = json.load(open(prof)).get("k_trace_hbm_bytes_per_launch")
+            try:  # PMC: HBM bytes per algorithmic byte of k_trace (tools/summarize_pmc.py), per launch like `achieved`
+                traffic = json.load(open(prof)).get("k_trace_hbm_bytes_per_algorithmic_byte") * alg_bytes / launches
             except Exception:
                 traffic = None
         out = {
@@ -194,6 +195,10 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes / launches, "avg_launch_ms": st.trace_ms / launches,
                 "launches": launches, "trace_share_of_step_time": trace_s / (st.kernel_ms * 1e-3) if st.kernel_ms else None,
+                # what a profiler sees for the same command: every k_trace launch of the process, warm-up included
+                # (the warm-up closes with its own tail of small launches, so its average is lower)
+                "launches_incl_warmup": launches + int(st_w.trace_launches),
+                "avg_launch_ms_incl_warmup": (st.trace_ms + st_w.trace_ms) / max(launches + int(st_w.trace_launches), 1),
                 "note": "achieved counts the reference traversal's ALGORITHMIC bytes (SURVEY.md 8d); the scene is L2-resident, so "
                         "traffic (HBM bytes per launch, PMC) is ~10x smaller and frac may exceed 1; PMC shows k_trace bound by VALU "
                         "issue (profiles/r01_v6_sq_summary.json, DESIGN.md 3.4)",

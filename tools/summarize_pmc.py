@@ -26,6 +26,17 @@ for d in (fetch_dir, write_dir, l2_dir):
             out.setdefault(kn, {})[cn] = {"dispatches": v[0], "sum": v[1], "avg_per_launch": v[1] / v[0]}
 b = json.load(open(bench))
 t = out["k_trace"]
+
+
+def run_line(d):
+    """the bench line the profiled command itself printed (tools/profile_round.sh keeps it in <dir>.log)"""
+    for line in reversed(open(d.rstrip("/") + ".log", errors="replace").read().splitlines()):
+        if line.startswith("{") and '"roofline"' in line:
+            return json.loads(line)
+    return None
+
+
+pr = run_line(fetch_dir)
 fetch = t["FETCH_SIZE"]["avg_per_launch"] * 1024
 write = t["WRITE_SIZE"]["avg_per_launch"] * 1024
 summary = {
@@ -41,7 +52,18 @@ summary = {
     "k_trace_l2_hit_rate": t["TCC_HIT_sum"]["sum"] / (t["TCC_HIT_sum"]["sum"] + t["TCC_MISS_sum"]["sum"]),
     "k_trace_algorithmic_bytes_per_launch": b["roofline"]["algorithmic_bytes_per_launch"],
 }
+# The launches of the profiled command (1 step + flush) are not those of the default run (4 steps + flush: the
+# tail passes come once per run), so the per-launch figure is carried over as HBM bytes per ALGORITHMIC byte of
+# the same run; bench.py multiplies it with its own algorithmic bytes per launch.
+ratio = None
+if pr:
+    alg_total = pr["roofline"]["algorithmic_bytes_per_launch"] * pr["roofline"]["launches"]
+    hbm_total = (2 * t["FETCH_SIZE"]["sum"] + t["WRITE_SIZE"]["sum"]) * 1024
+    ratio = hbm_total / alg_total
+    summary["profiled_run"] = {"launches": pr["roofline"]["launches"], "algorithmic_bytes_total": alg_total,
+                               "k_trace_hbm_bytes_total": hbm_total, "k_trace_dispatches_seen": t["FETCH_SIZE"]["dispatches"]}
+    summary["k_trace_hbm_bytes_per_algorithmic_byte"] = ratio
 json.dump(summary, open(os.path.join(ROOT, "profiles", tag + "_pmc_summary.json"), "w"), indent=1)
-json.dump({"k_trace_hbm_bytes_per_launch": 2 * fetch + write, "source": "profiles/%s_pmc_summary.json" % tag},
-          open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"))
+json.dump({"k_trace_hbm_bytes_per_algorithmic_byte": ratio, "k_trace_hbm_bytes_per_launch_of_profiled_run": 2 * fetch + write,
+           "source": "profiles/%s_pmc_summary.json" % tag}, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"))
 print({k: v for k, v in summary.items() if k.startswith("k_trace")})
