@@ -201,7 +201,7 @@ def main():
                 "avg_launch_ms_incl_warmup": (st.trace_ms + st_w.trace_ms) / max(launches + int(st_w.trace_launches), 1),
                 "note": "achieved counts the reference traversal's ALGORITHMIC bytes (SURVEY.md 8d); the scene is L2-resident, so "
                         "traffic (HBM bytes per launch, PMC) is ~10x smaller and frac may exceed 1; PMC shows k_trace bound by VALU "
-                        "issue (profiles/r01_v6_sq_summary.json, DESIGN.md 3.4)",
+                        "issue (profiles/r01_v7_sq_summary.json, DESIGN.md 3.4)",
             },
         }
         if world == 1 and not args.no_cpu_baseline:
