@@ -93,32 +93,45 @@ __global__ void k_init(PathState P) {
 }
 
 #define JADE_ARM_BLOCK 1024
+#define JADE_ARM_PER_THREAD 8
 // Lists every record that has work in this step (samples left to start, or a
 // path suspended by a previous step): the input of the first shade pass.
 __global__ __launch_bounds__(JADE_ARM_BLOCK) void k_arm(PathState P, uint32_t target_spp, uint32_t* active_out, QueueCtl* qc) {
-  __shared__ uint32_t sh_cnt[JADE_ARM_BLOCK / 64], sh_base;
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  bool want = false;
-  if (p < P.npix) {
-    const uint32_t st = P.stage[p] & 255u;
-    want = st != ST_IDLE || next_sample(P, p, P.done[p]).sidx < target_spp;
-  }
+  // a block lists JADE_ARM_PER_THREAD * 1024 consecutive records with ONE list atomic (same-address atomics
+  // cost ~12 ns each: at 534 M records one per 1024 was 6 ms), in record order
+  constexpr int NW = JADE_ARM_BLOCK / 64, NJ = JADE_ARM_PER_THREAD;
+  __shared__ uint32_t sh_cnt[NJ * NW + 1];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const unsigned long long m = __ballot(want);
-  const uint32_t off = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-  if (lane == 0) sh_cnt[w] = (uint32_t)__popcll(m);
+  const size_t base = (size_t)blockIdx.x * (JADE_ARM_BLOCK * NJ);
+  uint32_t wantm = 0, off[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const size_t p = base + (size_t)j * JADE_ARM_BLOCK + threadIdx.x;
+    bool want = false;
+    if (p < (size_t)P.npix) {
+      const uint32_t st = P.stage[p] & 255u;
+      want = st != ST_IDLE || next_sample(P, (int)p, P.done[p]).sidx < target_spp;
+    }
+    const unsigned long long m = __ballot(want);
+    off[j] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (want) wantm |= 1u << j;
+    if (lane == 0) sh_cnt[j * NW + w] = (uint32_t)__popcll(m);
+  }
   __syncthreads();
-  if (threadIdx.x == 0) {  // one list atomic per 1024 records: same-address atomics cost ~12 ns each
+  if (threadIdx.x == 0) {  // exclusive prefix over (j, wave), then the block's place in the list
     uint32_t tot = 0;
-    for (int i = 0; i < JADE_ARM_BLOCK / 64; ++i) tot += sh_cnt[i];
-    sh_base = tot ? atomicAdd(&qc->active, tot) : 0u;
+    for (int i = 0; i < NJ * NW; ++i) {
+      const uint32_t c = sh_cnt[i];
+      sh_cnt[i] = tot;
+      tot += c;
+    }
+    sh_cnt[NJ * NW] = tot ? atomicAdd(&qc->active, tot) : 0u;
   }
   __syncthreads();
-  if (want) {
-    uint32_t b = sh_base + off;
-    for (int i = 0; i < w; ++i) b += sh_cnt[i];
-    active_out[b] = (uint32_t)p;
-  }
+  const uint32_t blk = sh_cnt[NJ * NW];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+    if (wantm & (1u << j)) active_out[blk + sh_cnt[j * NW + w] + off[j]] = (uint32_t)(base + (size_t)j * JADE_ARM_BLOCK + threadIdx.x);
 }
 
 #ifndef JADE_CARRY_RECORDS
@@ -977,7 +990,7 @@ static int run_passes(jade_scene* s, uint32_t target_spp, bool may_carry, double
   // the records with work in this step
   uint32_t host_ctl[3] = {0, 0, 0};
   HIP_TRY(hipMemsetAsync(qc, 0, 12, s->stream));
-  hipLaunchKernelGGL(k_arm, dim3((unsigned)((npix + JADE_ARM_BLOCK - 1) / JADE_ARM_BLOCK)), dim3(JADE_ARM_BLOCK), 0, s->stream, s->ps, target_spp,
+  hipLaunchKernelGGL(k_arm, dim3((unsigned)(((size_t)npix + JADE_ARM_BLOCK * JADE_ARM_PER_THREAD - 1) / (JADE_ARM_BLOCK * JADE_ARM_PER_THREAD))), dim3(JADE_ARM_BLOCK), 0, s->stream, s->ps, target_spp,
                      s->b_active[0].as<uint32_t>(), qc);
   HIP_TRY(hipMemcpyAsync(host_ctl, qc, 12, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
@@ -1000,7 +1013,7 @@ static int run_passes(jade_scene* s, uint32_t target_spp, bool may_carry, double
     if (!lean_mode && !have_list) {
       cur = 0;
       HIP_TRY(hipMemsetAsync(qc, 0, 16, s->stream));
-      hipLaunchKernelGGL(k_arm, dim3((unsigned)((npix + JADE_ARM_BLOCK - 1) / JADE_ARM_BLOCK)), dim3(JADE_ARM_BLOCK), 0, s->stream, s->ps, target_spp,
+      hipLaunchKernelGGL(k_arm, dim3((unsigned)(((size_t)npix + JADE_ARM_BLOCK * JADE_ARM_PER_THREAD - 1) / (JADE_ARM_BLOCK * JADE_ARM_PER_THREAD))), dim3(JADE_ARM_BLOCK), 0, s->stream, s->ps, target_spp,
                          s->b_active[0].as<uint32_t>(), qc);
       have_list = true;
     }
