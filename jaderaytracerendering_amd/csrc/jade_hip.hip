@@ -141,9 +141,6 @@ __global__ __launch_bounds__(JADE_ARM_BLOCK) void k_arm(PathState P, uint32_t ta
 #define JADE_SHADE_BLOCK 512 /* threads per k_shade block: one queue + one list atomic per block (512: +1.8 % over 256; 1024: none) */
 #endif
 #define JADE_SHADE_NW (JADE_SHADE_BLOCK / 64)
-#ifndef JADE_SHADE_SORT
-#define JADE_SHADE_SORT 0
-#endif
 #ifndef JADE_SHADE_WAVES
 #define JADE_SHADE_WAVES 6 /* k_shade: 75 VGPRs, no spill (7 would spill 16 B).  +4 % over 5 when it runs alone, +-0 behind k_shade_lean */
 #endif
@@ -399,40 +396,7 @@ __global__ __launch_bounds__(JADE_SHADE_BLOCK, JADE_SHADE_WAVES) void k_shade(De
   const uint32_t n = n_dev ? *n_dev : n_host;
   if (blockIdx.x * blockDim.x >= n) return;  // block-uniform: the grid is sized for an upper bound of n_dev
   const uint32_t t_idx = blockIdx.x * blockDim.x + threadIdx.x;
-  int p = t_idx < n ? (int)list[t_idx] : P.npix;
-#if JADE_SHADE_SORT
-  {
-    // Deal the block's records to its threads by stage, so that a wave folds in ONE kind of ray result
-    // instead of running every branch of consume() for a few lanes each (which record a thread works on
-    // is free: a permutation inside the block).
-    constexpr int NB = 9;  // stages 0..7, and "no record"
-    __shared__ uint32_t sh_p[JADE_SHADE_BLOCK];
-    __shared__ uint32_t sh_h[NB * JADE_SHADE_NW + 1];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint32_t stg = p < P.npix ? (P.stage[p] & 255u) : 8u;
-    const uint32_t b = stg < 8u ? stg : 8u;
-    uint32_t rank = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < (uint32_t)NB; ++k) {
-      const unsigned long long m = __ballot(b == k);
-      if (b == k) rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-      if (lane == 0) sh_h[k * JADE_SHADE_NW + w] = (uint32_t)__popcll(m);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      uint32_t tot = 0;
-      for (int i = 0; i < NB * JADE_SHADE_NW; ++i) {
-        const uint32_t cnt = sh_h[i];
-        sh_h[i] = tot;
-        tot += cnt;
-      }
-    }
-    __syncthreads();
-    sh_p[sh_h[b * JADE_SHADE_NW + w] + rank] = (uint32_t)p;
-    __syncthreads();
-    p = (int)sh_p[threadIdx.x];
-  }
-#endif
+  const int p = t_idx < n ? (int)list[t_idx] : P.npix;
   ShadeCtx c;
   c.n_emit_rays = 0;
   c.c_primary = c.c_secondary = c.c_shaded = c.c_samples = 0;
