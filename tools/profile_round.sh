@@ -6,6 +6,7 @@ set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}
 tag=$1
 O=$R/gpurun_out/$tag
+rm -rf $O
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 900 python3 $R/bench.py > $O/bench.json 2> $O/bench.err

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, fetch_dir, write_dir, l2_dir, bench = sys.argv[1:6]
 out = {}
 for d in (fetch_dir, write_dir, l2_dir):
-    f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))[-1]
+    f = max(glob.glob(os.path.join(d, "*", "*counter_collection.csv")), key=os.path.getmtime)  # the newest run in that directory
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
         k = (r["Kernel_Name"].split("(")[0], r["Counter_Name"])
