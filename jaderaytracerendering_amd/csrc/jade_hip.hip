@@ -141,6 +141,9 @@ __global__ __launch_bounds__(JADE_ARM_BLOCK) void k_arm(PathState P, uint32_t ta
 #define JADE_SHADE_BLOCK 512 /* threads per k_shade block: one queue + one list atomic per block (512: +1.8 % over 256; 1024: none) */
 #endif
 #define JADE_SHADE_NW (JADE_SHADE_BLOCK / 64)
+#ifndef JADE_LEAN_BLOCK
+#define JADE_LEAN_BLOCK 512 /* threads per k_shade_lean block (1024 = half the list atomics, but 26 vs 20 ms per pass at 534 M records) */
+#endif
 #ifndef JADE_SHADE_WAVES
 #define JADE_SHADE_WAVES 6 /* k_shade: 75 VGPRs, no spill (7 would spill 16 B).  +4 % over 5 when it runs alone, +-0 behind k_shade_lean */
 #endif
@@ -319,12 +322,12 @@ static __device__ __forceinline__ void shade_record(const DevScene& S, const Pat
 
 // Queue the emitted rays, list the record for the next pass and/or for the full kernel: wave scans,
 // then ONE atomic per block for queue + list (not per wave: see DevCounters).
-template <bool LEAN>
+template <bool LEAN, int NW>  // NW: waves per block
 static __device__ __forceinline__ void shade_tail(const PathState& P, int p, uint32_t st, const ShadeCtx& c, bool defer,
                                                   uint32_t* active_out, uint32_t* heavy_out, uint32_t* queue, QueueCtl* qc,
                                                   DevCounters* ctr) {
-  __shared__ uint32_t sh_rays[JADE_SHADE_NW], sh_act[JADE_SHADE_NW], sh_def[JADE_SHADE_NW], sh_base[3];
-  __shared__ uint32_t sh_ctr[JADE_SHADE_NW][4];
+  __shared__ uint32_t sh_rays[NW], sh_act[NW], sh_def[NW], sh_base[3];
+  __shared__ uint32_t sh_ctr[NW][4];
   const int npix = P.npix;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   uint32_t total;
@@ -341,7 +344,7 @@ static __device__ __forceinline__ void shade_tail(const PathState& P, int p, uin
   __syncthreads();
   if (threadIdx.x == 0) {
     uint32_t tr = 0, ta = 0, td = 0;
-    for (int i = 0; i < JADE_SHADE_NW; ++i) {
+    for (int i = 0; i < NW; ++i) {
       tr += sh_rays[i];
       ta += sh_act[i];
       td += sh_def[i];
@@ -381,7 +384,7 @@ static __device__ __forceinline__ void shade_tail(const PathState& P, int p, uin
   __syncthreads();
   if (threadIdx.x < 4) {
     unsigned long long t = 0;
-    for (int i = 0; i < JADE_SHADE_NW; ++i) t += sh_ctr[i][threadIdx.x];
+    for (int i = 0; i < NW; ++i) t += sh_ctr[i][threadIdx.x];
     DevCounters* cs = ctr + (blockIdx.x % JADE_CTR_SHARDS);
     unsigned long long* dst = threadIdx.x == 0 ? &cs->rays_primary : threadIdx.x == 1 ? &cs->rays_secondary : threadIdx.x == 2 ? &cs->shaded_hits : &cs->samples;
     if (t) atomicAdd(dst, t);
@@ -403,14 +406,14 @@ __global__ __launch_bounds__(JADE_SHADE_BLOCK, JADE_SHADE_WAVES) void k_shade(De
   uint32_t st;
   bool defer;
   shade_record<false>(S, P, R, tile_ids, target_spp, p, c, st, defer);
-  shade_tail<false>(P, p, st, c, false, active_out, nullptr, queue, qc, ctr);
+  shade_tail<false, JADE_SHADE_NW>(P, p, st, c, false, active_out, nullptr, queue, qc, ctr);
 }
 
 // The lean shade kernel: camera rays, the sky and pure mirrors only — what most records of most
 // scenes do most of the time — in 56 VGPRs (8 waves/SIMD; the kernel is latency-bound).  It walks
 // ALL records in record order (no list: perfectly coalesced, and nothing to fragment) and hands
 // every record that needs anything else to k_shade through heavy_out / qc->heavy.
-__global__ __launch_bounds__(JADE_SHADE_BLOCK) void k_shade_lean(DevScene S, PathState P, RenderConst R, const int32_t* tile_ids,
+__global__ __launch_bounds__(JADE_LEAN_BLOCK) void k_shade_lean(DevScene S, PathState P, RenderConst R, const int32_t* tile_ids,
                                                                  uint32_t target_spp, uint32_t* heavy_out, uint32_t* queue,
                                                                  QueueCtl* qc, DevCounters* ctr) {
   const int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);  // >= npix: no record (shade_record checks)
@@ -420,7 +423,7 @@ __global__ __launch_bounds__(JADE_SHADE_BLOCK) void k_shade_lean(DevScene S, Pat
   uint32_t st;
   bool defer;
   shade_record<true>(S, P, R, tile_ids, target_spp, p, c, st, defer);
-  shade_tail<true>(P, p, st, c, defer, nullptr, heavy_out, queue, qc, ctr);
+  shade_tail<true, JADE_LEAN_BLOCK / 64>(P, p, st, c, defer, nullptr, heavy_out, queue, qc, ctr);
 }
 
 #ifndef JADE_TRACE_PROFILE
@@ -1022,7 +1025,7 @@ static int run_passes(jade_scene* s, uint32_t target_spp, bool may_carry, double
     const unsigned nb = (n_active + JADE_SHADE_BLOCK - 1) / JADE_SHADE_BLOCK;
     if (lean_mode) {
       // b_active[1] carries the hand-over list; no active list is kept in this mode
-      hipLaunchKernelGGL(k_shade_lean, dim3((unsigned)((npix + JADE_SHADE_BLOCK - 1) / JADE_SHADE_BLOCK)), dim3(JADE_SHADE_BLOCK), 0,
+      hipLaunchKernelGGL(k_shade_lean, dim3((unsigned)((npix + JADE_LEAN_BLOCK - 1) / JADE_LEAN_BLOCK)), dim3(JADE_LEAN_BLOCK), 0,
                          s->stream, s->dev, s->ps, s->rc, s->b_tiles.as<int32_t>(), target_spp, s->b_active[1].as<uint32_t>(),
                          s->b_queue.as<uint32_t>(), qc, s->b_ctr.as<DevCounters>());
       if (log_passes) HIP_TRY(hipEventRecord(sm, s->stream));
