@@ -3,17 +3,22 @@
 // Replaces PathTrace.cu:1618-1741 (upload, constants, RNG init, the single
 // render_pixel launch, sync, download).  Kernel structure (one HIP stream):
 //
-//   k_init     seeds the per-pixel Wang-hash states, clears the sums
-//   k_shade    one lane per owned pixel: fold last pass's hit results into the
-//              path, start the next sample when a path ends, sample the next
-//              bounce, emit its rays into a compacted queue (wave prefix sum +
-//              one atomic per wave)
-//   k_trace    persistent workgroups pull 64-ray batches from the queue and run
-//              the BVH traversal (jade_trace.h) — the dominant kernel
-//   k_resolve  mean, ACES, gamma, BGR8 pack (PathTrace.cu:1457-1473)
+//   k_init        resets the path records, clears the partial sums
+//   k_arm         lists the records that have work in a step (record order)
+//   k_shade_lean  camera rays, the sky and pure mirrors, over ALL records in record
+//                 order (52 VGPRs, 8 waves/SIMD): folds last pass's hit results
+//                 into the path, starts the next sample when a path ends, emits
+//                 rays into a compacted queue (wave prefix sums + one 64-bit
+//                 atomic per block); hands every other record to k_shade
+//   k_shade       every branch of pathTracing, over the hand-over list or (once few
+//                 records are active) over the active list
+//   k_trace       persistent workgroups claim chunks of the queue and run the BVH
+//                 traversal (jade_trace.h) — the dominant kernel
+//   k_resolve     adds the partial sums; mean, ACES, gamma, BGR8 pack (PathTrace.cu:1457-1473)
 //
-// shade/trace alternate until a shade pass emits nothing (every pixel has
-// finished its samples).  There is no CPU fallback: if HIP is unavailable the
+// shade/trace alternate until a shade pass emits nothing (every path record has
+// finished its samples), or until so few are active that the step hands them to the
+// next one (jade_render_flush).  There is no CPU fallback: if HIP is unavailable the
 // entry points return JADE_ERR_DEVICE.
 #include <hip/hip_runtime.h>
 

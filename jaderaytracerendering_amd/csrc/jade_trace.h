@@ -12,21 +12,20 @@
 //   - one ray per lane, rays taken from a compacted queue by persistent
 //     workgroups: a wave claims a chunk with one atomic and refills its idle
 //     lanes from that chunk, so short rays do not leave lanes idle behind long ones;
-//   - the unit of work per loop iteration is one primitive (a node visit or
-//     one triangle test), not a whole 8-triangle leaf;
+//   - a lane walks nodes without stopping at leaves (a leaf it meets goes into a small
+//     FIFO) and tests triangles from the head of that FIFO; a wave iteration runs ONE
+//     kind of work for all lanes that have some (see RayState);
 //   - the near child is followed directly and only the far child is pushed,
 //     which visits nodes in exactly the reference's order with half the stack
 //     traffic;
-//   - the stack lives in LDS as stack[level][lane] (bank-conflict free: lane
-//     l always hits bank l % 32 of its half-wave); 12 levels cover every ray of
-//     the benchmark scenes, deeper levels spill to a per-lane global area
-//     (JADE_BVH_STACK_CAPACITY entries in total);
-//   - the parts of the ray state that the triangle test does not read (1/dir,
-//     the best hit so far) live in the same LDS column, so the kernel needs 60
-//     VGPRs and a SIMD holds 8 waves: the kernel is latency-bound, waves are
-//     what hides the latency;
-//   - both children's boxes come from the parent's 64-B record, so a node
-//     visit is four 16-B loads of one line (see jade_device.h);
+//   - a lane's column of LDS words, word[k][lane] (bank-conflict free: lane l always
+//     hits bank l % 32 of its half-wave), holds the stack (8 levels cover 99.6 % of
+//     the rays of the benchmark scenes, deeper levels spill to a per-lane global
+//     area, JADE_BVH_STACK_CAPACITY entries in total), the leaf FIFO, and the parts of
+//     the ray state that the triangle test does not read (1/dir, the best hit);
+//   - both children's boxes come from the parent's 64-B record, interleaved so that
+//     the two slab tests — and the p1/p2 half of the triangle test — run as packed
+//     fp32 (v_pk_*_f32): the kernel is VALU-bound (see jade_device.h);
 //   - 1/dir and normalize(dir), which the reference recomputes per node and
 //     per triangle (:710, :759), are computed once per ray — same values.
 #pragma once
