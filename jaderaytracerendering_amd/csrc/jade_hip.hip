@@ -666,7 +666,10 @@ struct jade_scene {
   int trace_blocks = 0;
   int64_t spp_done = 0;
   bool tail_pending = false;  // the last step left its longest paths unfinished (jade_render_flush)
+  hipEvent_t ev[7] = {};      // run_passes' timing events, made once (ev0, ev1, ta, tb, sa, sb, sm)
   ~jade_scene() {
+    for (hipEvent_t e : ev)
+      if (e) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
   }
 };
@@ -985,11 +988,9 @@ static hipError_t sum_counters(jade_scene* s, DevCounters* out) {
 static int run_passes(jade_scene* s, uint32_t target_spp, bool may_carry, double* ms_out, double* trace_ms_out, uint64_t* launches_out) {
   const int npix = s->ps.npix;
   QueueCtl* qc = s->b_ctl.as<QueueCtl>();
-  hipEvent_t ev0, ev1, ta, tb;
-  HIP_TRY(hipEventCreate(&ev0));
-  HIP_TRY(hipEventCreate(&ev1));
-  HIP_TRY(hipEventCreate(&ta));
-  HIP_TRY(hipEventCreate(&tb));
+  for (hipEvent_t& e : s->ev)
+    if (!e) HIP_TRY(hipEventCreate(&e));
+  const hipEvent_t ev0 = s->ev[0], ev1 = s->ev[1], ta = s->ev[2], tb = s->ev[3], sa = s->ev[4], sb = s->ev[5], sm = s->ev[6];
   HIP_TRY(hipEventRecord(ev0, s->stream));
   bool trace_pending = false, carried = false;
   double trace_ms = 0;
@@ -1011,11 +1012,7 @@ static int run_passes(jade_scene* s, uint32_t target_spp, bool may_carry, double
   // over the active list, which k_arm rebuilds once at the switch.  JADE_SHADE_SPLIT=0: always the list.
   const bool split_ok = !(getenv("JADE_SHADE_SPLIT") && atoi(getenv("JADE_SHADE_SPLIT")) == 0);
   bool have_list = true;  // b_active[cur] lists the active records
-  hipEvent_t sa, sb, sm;
   float shade_ms = 0, lean_ms = 0;
-  HIP_TRY(hipEventCreate(&sa));
-  HIP_TRY(hipEventCreate(&sb));
-  HIP_TRY(hipEventCreate(&sm));
   while (n_active) {
     const bool lean_mode = split_ok && (uint64_t)n_active * 4 >= (uint64_t)npix;
     if (!lean_mode && !have_list) {
@@ -1098,10 +1095,6 @@ static int run_passes(jade_scene* s, uint32_t target_spp, bool may_carry, double
   HIP_TRY(hipEventSynchronize(ev1));
   float ms = 0;
   HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
-  (void)hipEventDestroy(ev0);
-  (void)hipEventDestroy(ev1);
-  (void)hipEventDestroy(ta);
-  (void)hipEventDestroy(tb);
   *ms_out = ms;
   *trace_ms_out = trace_ms;
   *launches_out = launches;
