@@ -916,15 +916,16 @@ int jade_render_begin(jade_scene* s, const jade_render_params* rp) {
   mem_free += s->b_state.bytes + s->b_queue.bytes + s->b_active[0].bytes + s->b_active[1].bytes;  // ours to reuse
   const double budget = JADE_RECORD_MEMORY * (double)mem_free - sums_bytes;
   int rpp = JADE_SAMPLE_LANES;
+  // (3 * npix must fit an int: the three planes of a per-record vec3 are indexed with int arithmetic)
   while (rpp > 1 && ((double)npx64 * rpp * bytes_per_record > budget || npx64 * rpp * nslots >= ((int64_t)1 << 32) ||
-                     npx64 * rpp >= ((int64_t)1 << 31)))
+                     npx64 * rpp * 3 >= ((int64_t)1 << 31)))
     rpp >>= 1;
   if (const char* e = getenv("JADE_RECORDS_PER_PIXEL")) {  // test hook: results must not depend on it
     int v = atoi(e);
     if (v >= 1 && v <= JADE_SAMPLE_LANES && (v & (v - 1)) == 0) rpp = v;
   }
   const int64_t npix64 = npx64 * rpp;
-  if (npix64 * nslots >= ((int64_t)1 << 32) || npix64 >= ((int64_t)1 << 31))
+  if (npix64 * nslots >= ((int64_t)1 << 32) || npix64 * 3 >= ((int64_t)1 << 31))
     return fail(JADE_ERR_UNSUPPORTED, "pixels x records x (emitters + 2) exceeds the 32-bit ray-slot index");
   if (sums_bytes + (double)npix64 * bytes_per_record > 0.95 * (double)mem_free)
     return fail(JADE_ERR_NOMEM, "frame does not fit the device memory (partial sums + one record per pixel)");
