@@ -12,7 +12,11 @@ render, not K restarts; the defaults (4 steps x 1024 spp) are exactly the
 4096-spp render BASELINE.json names.  Multi-GPU: the image's 16x16 tiles are dealt
 round-robin to the ranks and the samples per step scale with N, so per-GPU work
 per step is constant ("weak"); after the timed steps the framebuffer is
-collected with ONE gather (RCCL), timed separately as gather_ms.
+collected with ONE gather (RCCL), timed separately as gather_ms.  A step may hand
+its last few unfinished paths to the next step (jade_render_flush, jade_rt.h); the
+warm-up is flushed before the clock starts and the K timed steps are flushed before
+it stops, so every sample of the K steps — `samples` = K * spp * pixels, and all
+their rays — is computed inside the timed region.
 
 value = (primary + secondary rays traced by all ranks in the K timed steps)
         / max-over-ranks wall time, in Mray/s.  A ray = one hitBVH query.
