@@ -68,15 +68,22 @@ struct NextSample {
   uint32_t sidx;  // global sample index (jade_rt.h)
   int pixel;      // owned-pixel index it belongs to
 };
+// (m, home) = (p / npx, p % npx): where record p sits; computed once per thread, an integer division each.
+// rpp and JADE_SAMPLE_LANES are powers of two, so everything else is shifts — and the 64-bit modulo of the
+// pixel rotation only runs when rotation is on (it is not, by default).
+static __device__ __forceinline__ NextSample next_sample_mh(const PathState& P, uint32_t m, uint32_t home, uint32_t done) {
+  const uint32_t rpp_log2 = 31u - (uint32_t)__clz(P.rpp);
+  const uint32_t per_log2 = (31u - (uint32_t)__clz(JADE_SAMPLE_LANES)) - rpp_log2;  // samples per record per block = LANES / rpp
+  const uint32_t blk = done >> per_log2, n = done - (blk << per_log2);
+  NextSample r;
+  r.sidx = JADE_SAMPLE_LANES * blk + m + (n << rpp_log2);
+  r.pixel = P.stride == 0 ? (int)home
+                          : (int)(((unsigned long long)home + (unsigned long long)n * (uint32_t)P.stride) % (uint32_t)P.npx);
+  return r;
+}
 static __device__ __forceinline__ NextSample next_sample(const PathState& P, int p, uint32_t done) {
   const uint32_t m = (uint32_t)p / (uint32_t)P.npx;
-  const uint32_t home = (uint32_t)p - m * (uint32_t)P.npx;
-  const uint32_t per = JADE_SAMPLE_LANES / (uint32_t)P.rpp;  // samples per record per block
-  const uint32_t blk = done / per, n = done - blk * per;
-  NextSample r;
-  r.sidx = JADE_SAMPLE_LANES * blk + m + (uint32_t)P.rpp * n;
-  r.pixel = (int)(((unsigned long long)home + (unsigned long long)n * (uint32_t)P.stride) % (uint32_t)P.npx);
-  return r;
+  return next_sample_mh(P, m, (uint32_t)p - m * (uint32_t)P.npx, done);
 }
 static __device__ __forceinline__ bool pixel_xy_t(const RenderConst& R, int tid, int pixel, int* x, int* y) {
   int l = pixel & 255;
@@ -172,7 +179,8 @@ static __device__ __forceinline__ void shade_record(const DevScene& S, const Pat
   const int hit0 = P.hit[pp];
   const size_t pl0 = (size_t)P.nslots * npix;
   const jvec3 dir0 = jv(P.dir[pp], P.dir[pl0 + pp], P.dir[2 * pl0 + pp]);
-  const int home_pix = pp % P.npx;
+  const uint32_t rec_m = (uint32_t)pp / (uint32_t)P.npx;
+  const int home_pix = (int)((uint32_t)pp - rec_m * (uint32_t)P.npx);
   const int tid0 = tile_ids[home_pix >> 8];
   if (p < npix) st = word & 255u;
   if (st != ST_INVALID) {
@@ -254,7 +262,7 @@ static __device__ __forceinline__ void shade_record(const DevScene& S, const Pat
         // final_result = final_result + color (PathTrace.cu:1454), into the partial sum of
         // this sample's (pixel, lane): only this record touches it in this block
         {
-          const NextSample cs = next_sample(P, p, done);  // the sample that just ended
+          const NextSample cs = next_sample_mh(P, rec_m, (uint32_t)home_pix, done);  // the sample that just ended
           const size_t si = (size_t)(cs.sidx % JADE_SAMPLE_LANES) * (size_t)P.npx + (size_t)cs.pixel;
           const size_t sn = (size_t)JADE_SAMPLE_LANES * (size_t)P.npx;
           st3w(P.sum, sn, si, jv_add(ld3w(P.sum, sn, si), color));
@@ -280,10 +288,10 @@ static __device__ __forceinline__ void shade_record(const DevScene& S, const Pat
       if (st == ST_IDLE) {
         // next sample of this record; samples of out-of-image pixels (edge tiles) are skipped
         int x, y;
-        NextSample ns = next_sample(P, p, done);
+        NextSample ns = next_sample_mh(P, rec_m, (uint32_t)home_pix, done);
         while (ns.sidx < target_spp && !pixel_xy_t(R, ns.pixel == home_pix ? tid0 : tile_ids[ns.pixel >> 8], ns.pixel, &x, &y)) {
           done += 1;
-          ns = next_sample(P, p, done);
+          ns = next_sample_mh(P, rec_m, (uint32_t)home_pix, done);
         }
         if (ns.sidx >= target_spp) break;
         // camera ray, PathTrace.cu:1428-1437
