@@ -34,7 +34,7 @@ extern "C" {
 
 /* bump whenever a struct layout or a documented semantic changes; callers compare
  * jade_abi_version() with the value they were compiled against */
-#define JADE_ABI_VERSION 3
+#define JADE_ABI_VERSION 4
 
 /* status codes */
 #define JADE_OK 0
@@ -135,6 +135,12 @@ typedef struct jade_render_params {
   int32_t tile_rank, tile_nranks;
   int32_t device_id;     /* HIP device ordinal (ignored by the oracle) */
   int32_t threads;       /* oracle: worker threads (0 = all cores); HIP: ignored */
+  /* HIP: most device memory (bytes) this render may hold for path records and partial sums; 0 = the
+   * default (60 % of what is free at jade_render_begin).  The module keeps as many of a pixel's samples
+   * in flight as fit - never more than `spp` rounded up to a power of two, so a small render stays
+   * small; a progressive host that will add many samples per step passes that number in `spp` here.
+   * The image does not depend on either.  Oracle: ignored. */
+  uint64_t max_state_bytes;
 } jade_render_params;
 
 /* Exact integer work counters; the oracle's and the HIP module's must be
@@ -152,6 +158,11 @@ typedef struct jade_stats {
    * stream, summed over launches; oracle: 0) — feeds the roofline figure */
   double trace_ms;
   uint64_t trace_launches;
+  /* rays_secondary by call site (exact; oracle == HIP): NEE shadow rays (PathTrace.cu:956, 1096, 1292),
+   * environment-visibility rays (:980, 1123, 1316), indirect rays (:1003, 1150, 1339), mirror rays
+   * (:1383), refraction rays (:1202, 1241) */
+  uint64_t rays_shadow, rays_env, rays_indirect, rays_mirror, rays_refract;
+  uint64_t host_syncs;     /* HIP: times the host waited for the device inside step/flush; oracle: 0 */
 } jade_stats;
 
 typedef struct jade_scene jade_scene; /* opaque */

@@ -6,7 +6,7 @@ reference device structs, PathTrace.cu:327-351).
 """
 import ctypes as C
 
-JADE_ABI_VERSION = 3
+JADE_ABI_VERSION = 4
 JADE_SAMPLE_LANES = 1024
 JADE_OK, JADE_ERR_INVALID, JADE_ERR_DEVICE, JADE_ERR_NOMEM, JADE_ERR_UNSUPPORTED = range(5)
 DIFFUSE, MIRROR = 0, 1
@@ -58,6 +58,7 @@ class RenderParams(C.Structure):
         ("eye", f3), ("camera", f16),
         ("tile_rank", C.c_int32), ("tile_nranks", C.c_int32),
         ("device_id", C.c_int32), ("threads", C.c_int32),
+        ("max_state_bytes", C.c_uint64),
     ]
 
 
@@ -68,6 +69,8 @@ class Stats(C.Structure):
         ("shaded_hits", C.c_uint64), ("samples", C.c_uint64),
         ("kernel_ms", C.c_double),
         ("trace_ms", C.c_double), ("trace_launches", C.c_uint64),
+        ("rays_shadow", C.c_uint64), ("rays_env", C.c_uint64), ("rays_indirect", C.c_uint64),
+        ("rays_mirror", C.c_uint64), ("rays_refract", C.c_uint64), ("host_syncs", C.c_uint64),
     ]
 
     def as_dict(self):

@@ -313,7 +313,15 @@ static __device__ __forceinline__ void shade_record(const DevScene& S, const Pat
       }
       break;  // a pending stage that just emitted (refraction loop)
     }
-    if (st != ST_PRIMARY) c.c_secondary += (uint32_t)c.n_emit_rays;
+    if (st != ST_PRIMARY && c.n_emit_rays) {  // the secondary rays of this pass by hitBVH call site (jade_rt.h)
+      if (st == ST_DIFFUSE || st == ST_BSSRDF) {
+        const uint32_t ind = (c.flags & STF_RR) ? 1u : 0u;
+        c.c_cls += 1u | (ind << 8);  // one environment ray always, the indirect ray if the roulette passed
+        c.c_shadow += (uint32_t)c.n_emit_rays - 1u - ind;
+      } else {
+        c.c_cls += st == ST_MIRROR ? (1u << 16) : (1u << 24);
+      }
+    }
     P.rng[p] = c.rng;
     P.done[p] = done;
     P.stage[p] = st | (c.depth << 8) | (c.flags << 16);
@@ -340,7 +348,7 @@ static __device__ __forceinline__ void shade_tail(const PathState& P, int p, uin
                                                   uint32_t* active_out, uint32_t* heavy_out, uint32_t* queue, QueueCtl* qc,
                                                   DevCounters* ctr) {
   __shared__ uint32_t sh_rays[NW], sh_act[NW], sh_def[NW], sh_base[3];
-  __shared__ uint32_t sh_ctr[NW][4];
+  __shared__ uint32_t sh_ctr[NW][8];
   const int npix = P.npix;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   uint32_t total;
@@ -386,21 +394,27 @@ static __device__ __forceinline__ void shade_tail(const PathState& P, int p, uin
     }
   }
   // work counters: per wave into LDS, then one set of atomics per block
-  const uint32_t s0 = (uint32_t)wave_sum_u32(c.c_primary), s1 = (uint32_t)wave_sum_u32(c.c_secondary),
-                 s2 = (uint32_t)wave_sum_u32(c.c_shaded), s3 = (uint32_t)wave_sum_u32(c.c_samples);
+  const uint32_t s0 = (uint32_t)wave_sum_u32(c.c_primary), s1 = (uint32_t)wave_sum_u32(c.c_shadow),
+                 s2 = (uint32_t)wave_sum_u32(c.c_shaded), s3 = (uint32_t)wave_sum_u32(c.c_samples),
+                 s4 = (uint32_t)wave_sum_u32(c.c_cls);  // four byte-wide sums of at most 64 each: no carry between them
   if (lane == 0) {
     sh_ctr[w][0] = s0;
     sh_ctr[w][1] = s1;
     sh_ctr[w][2] = s2;
     sh_ctr[w][3] = s3;
+    sh_ctr[w][4] = s4 & 255u;
+    sh_ctr[w][5] = (s4 >> 8) & 255u;
+    sh_ctr[w][6] = (s4 >> 16) & 255u;
+    sh_ctr[w][7] = s4 >> 24;
   }
   __syncthreads();
-  if (threadIdx.x < 4) {
+  if (threadIdx.x < 8) {
     unsigned long long t = 0;
     for (int i = 0; i < NW; ++i) t += sh_ctr[i][threadIdx.x];
     DevCounters* cs = ctr + (blockIdx.x % JADE_CTR_SHARDS);
-    unsigned long long* dst = threadIdx.x == 0 ? &cs->rays_primary : threadIdx.x == 1 ? &cs->rays_secondary : threadIdx.x == 2 ? &cs->shaded_hits : &cs->samples;
-    if (t) atomicAdd(dst, t);
+    // word of DevCounters: primary 0, shadow 1, shaded 4, samples 5, env / indirect / mirror / refract 8-11
+    const int i = (int)threadIdx.x, word = i < 2 ? i : i < 4 ? i + 2 : i + 4;
+    if (t) atomicAdd(reinterpret_cast<unsigned long long*>(cs) + word, t);
   }
 }
 
@@ -415,7 +429,7 @@ __global__ __launch_bounds__(JADE_SHADE_BLOCK, JADE_SHADE_WAVES) void k_shade(De
   const int p = t_idx < n ? (int)list[t_idx] : P.npix;
   ShadeCtx c;
   c.n_emit_rays = 0;
-  c.c_primary = c.c_secondary = c.c_shaded = c.c_samples = 0;
+  c.c_primary = c.c_shadow = c.c_shaded = c.c_samples = c.c_cls = 0;
   uint32_t st;
   bool defer;
   shade_record<false>(S, P, R, tile_ids, target_spp, p, c, st, defer);
@@ -432,7 +446,7 @@ __global__ __launch_bounds__(JADE_LEAN_BLOCK) void k_shade_lean(DevScene S, Path
   const int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);  // >= npix: no record (shade_record checks)
   ShadeCtx c;
   c.n_emit_rays = 0;
-  c.c_primary = c.c_secondary = c.c_shaded = c.c_samples = 0;
+  c.c_primary = c.c_shadow = c.c_shaded = c.c_samples = c.c_cls = 0;
   uint32_t st;
   bool defer;
   shade_record<true>(S, P, R, tile_ids, target_spp, p, c, st, defer);
@@ -487,6 +501,7 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
       if (wb) {
         const int32_t best = ray_best_index(stk);
         P.hit[my_e] = best;
+        if (P.hdist) P.hdist[my_e] = lds_getf(stk, LW_BEST_DIST);  // wave-uniform: only jade_trace_rays asks for it
         if (best >= 0) {  // the hit point of a miss is never read
           const jvec3 hp = ray_hit_point(stk);
           float* hb = P.hpt + my_e;
@@ -651,10 +666,19 @@ struct DevBuf {
   ~DevBuf() { if (p) (void)hipFree(p); }
   hipError_t alloc(size_t n) {
     if (p) { (void)hipFree(p); p = nullptr; }
-    bytes = n;
-    return hipMalloc(&p, n ? n : 16);
+    bytes = 0;
+    const hipError_t e = hipMalloc(&p, n ? n : 16);
+    if (e == hipSuccess) bytes = n;
+    else p = nullptr;
+    return e;
   }
   template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct DevEvent {  // an event that is destroyed on every return path
+  hipEvent_t e = nullptr;
+  ~DevEvent() { if (e) (void)hipEventDestroy(e); }
+  hipError_t create() { return hipEventCreate(&e); }
 };
 
 struct jade_scene {
@@ -675,18 +699,26 @@ struct jade_scene {
   int64_t spp_done = 0;
   bool tail_pending = false;  // the last step left its longest paths unfinished (jade_render_flush)
   hipEvent_t ev[7] = {};      // run_passes' timing events, made once (ev0, ev1, ta, tb, sa, sb, sm)
+  hipEvent_t ev_resolve = nullptr;  // jade_render_resolve_tiles_device: caller's stream -> scene stream
+  uint64_t host_syncs = 0;    // host waits inside step/flush since the last advance() reported them
   ~jade_scene() {
+    if (ev_resolve) (void)hipEventDestroy(ev_resolve);
     for (hipEvent_t e : ev)
       if (e) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
   }
 };
 
+// Copies on `stream` and waits for it: the scene's stream is non-blocking, so a copy on the null stream would
+// not be ordered before the kernels launched on it.
 template <class T>
-static hipError_t upload(DevBuf& b, const T* src, size_t count) {
+static hipError_t upload(DevBuf& b, const T* src, size_t count, hipStream_t stream) {
   hipError_t e = b.alloc(sizeof(T) * count);
   if (e != hipSuccess) return e;
-  if (count) e = hipMemcpy(b.p, src, sizeof(T) * count, hipMemcpyHostToDevice);
+  if (count) {
+    e = hipMemcpyAsync(b.p, src, sizeof(T) * count, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  }
   return e;
 }
 
@@ -806,14 +838,14 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
   s->n_emit = d->n_emit;
   s->bvh_depth = depth;
   hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
-  if (e == hipSuccess) e = upload(s->b_nodes, nodes.data(), nodes.size());
-  if (e == hipSuccess) e = upload(s->b_tverts, tverts.data(), tverts.size());
-  if (e == hipSuccess) e = upload(s->b_tris, d->triangles, (size_t)d->n_triangles);
-  if (e == hipSuccess) e = upload(s->b_emit, d->emit_indices, (size_t)d->n_emit);
-  if (e == hipSuccess) e = upload(s->b_mapping, d->index_mapping, (size_t)d->n_triangles);
-  if (e == hipSuccess) e = upload(s->b_prefix, d->prefix_area, (size_t)d->n_triangles);
-  if (e == hipSuccess) e = upload(s->b_segs, d->obj_segs, (size_t)d->n_objects);
-  if (e == hipSuccess) e = upload(s->b_env, d->env_rgb, (size_t)3 * d->env_width * d->env_height);
+  if (e == hipSuccess) e = upload(s->b_nodes, nodes.data(), nodes.size(), s->stream);
+  if (e == hipSuccess) e = upload(s->b_tverts, tverts.data(), tverts.size(), s->stream);
+  if (e == hipSuccess) e = upload(s->b_tris, d->triangles, (size_t)d->n_triangles, s->stream);
+  if (e == hipSuccess) e = upload(s->b_emit, d->emit_indices, (size_t)d->n_emit, s->stream);
+  if (e == hipSuccess) e = upload(s->b_mapping, d->index_mapping, (size_t)d->n_triangles, s->stream);
+  if (e == hipSuccess) e = upload(s->b_prefix, d->prefix_area, (size_t)d->n_triangles, s->stream);
+  if (e == hipSuccess) e = upload(s->b_segs, d->obj_segs, (size_t)d->n_objects, s->stream);
+  if (e == hipSuccess) e = upload(s->b_env, d->env_rgb, (size_t)3 * d->env_width * d->env_height, s->stream);
   if (e == hipSuccess) e = s->b_ctl.alloc(sizeof(QueueCtl));
   if (e == hipSuccess) e = s->b_ctr.alloc(sizeof(DevCounters) * JADE_CTR_SHARDS);
   if (e != hipSuccess) {
@@ -847,7 +879,10 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
   }
   // persistent trace grid: as many blocks per CU as registers and the LDS columns (20 KB/block) allow
   hipDeviceProp_t prop;
-  HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+  if (hipError_t pe = hipGetDeviceProperties(&prop, device_id); pe != hipSuccess) {
+    delete s;
+    return fail(JADE_ERR_DEVICE, std::string("hipGetDeviceProperties: ") + hipGetErrorString(pe));
+  }
   int per_cu = 0;
   (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace, JADE_TRACE_BLOCK, 0);
   if (per_cu < 1) per_cu = 1;
@@ -922,8 +957,15 @@ int jade_render_begin(jade_scene* s, const jade_render_params* rp) {
   size_t mem_free = 0, mem_total = 0;
   HIP_TRY(hipMemGetInfo(&mem_free, &mem_total));
   mem_free += s->b_state.bytes + s->b_queue.bytes + s->b_active[0].bytes + s->b_active[1].bytes;  // ours to reuse
-  const double budget = JADE_RECORD_MEMORY * (double)mem_free - sums_bytes;
+  // the caller's bound (jade_render_params.max_state_bytes) replaces the default share of the free memory
+  double state_budget = JADE_RECORD_MEMORY * (double)mem_free;
+  if (rp->max_state_bytes) state_budget = std::min((double)rp->max_state_bytes, 0.95 * (double)mem_free);
+  const double budget = state_budget - sums_bytes;
+  // never more records per pixel than samples this render was announced with (rounded up to a power of two):
+  // a 64-spp render of a small image must not claim, clear and scan gigabytes of records that never get a sample
   int rpp = JADE_SAMPLE_LANES;
+  if (rp->spp > 0)
+    for (rpp = 1; rpp < rp->spp && rpp < JADE_SAMPLE_LANES;) rpp <<= 1;
   // (3 * npix must fit an int: the three planes of a per-record vec3 are indexed with int arithmetic)
   while (rpp > 1 && ((double)npx64 * rpp * bytes_per_record > budget || npx64 * rpp * nslots >= ((int64_t)1 << 32) ||
                      npx64 * rpp * 3 >= ((int64_t)1 << 31)))
@@ -935,8 +977,9 @@ int jade_render_begin(jade_scene* s, const jade_render_params* rp) {
   const int64_t npix64 = npx64 * rpp;
   if (npix64 * nslots >= ((int64_t)1 << 32) || npix64 * 3 >= ((int64_t)1 << 31))
     return fail(JADE_ERR_UNSUPPORTED, "pixels x records x (emitters + 2) exceeds the 32-bit ray-slot index");
-  if (sums_bytes + (double)npix64 * bytes_per_record > 0.95 * (double)mem_free)
-    return fail(JADE_ERR_NOMEM, "frame does not fit the device memory (partial sums + one record per pixel)");
+  if (sums_bytes + (double)npix64 * bytes_per_record > (rp->max_state_bytes ? std::max(state_budget, 0.0) : 0.95 * (double)mem_free))
+    return fail(JADE_ERR_NOMEM, rp->max_state_bytes ? "frame does not fit max_state_bytes (partial sums + one record per pixel)"
+                                                    : "frame does not fit the device memory (partial sums + one record per pixel)");
   if (getenv("JADE_LOG_PASSES"))
     fprintf(stderr, "[jade] %lld pixels x %d records, %.1f GB of path state + %.1f GB of partial sums (%.0f GB free)\n", (long long)npx64,
             rpp, npix64 * bytes_per_record / 1e9, sums_bytes / 1e9, mem_free / 1e9);
@@ -955,7 +998,7 @@ int jade_render_begin(jade_scene* s, const jade_render_params* rp) {
   int rc = setup_state(s, (int)npx64, rpp, nslots);
   if (rc) return rc;
   memcpy(s->ps.eye, rp->eye, sizeof s->ps.eye);
-  HIP_TRY(upload(s->b_tiles, s->tile_ids.data(), s->tile_ids.size()));
+  HIP_TRY(upload(s->b_tiles, s->tile_ids.data(), s->tile_ids.size(), s->stream));
   HIP_TRY(hipMemsetAsync(s->b_ctr.p, 0, sizeof(DevCounters) * JADE_CTR_SHARDS, s->stream));
   hipLaunchKernelGGL(k_init, dim3((unsigned)((npix64 + 255) / 256)), dim3(256), 0, s->stream, s->ps);
   HIP_TRY(hipGetLastError());
@@ -976,12 +1019,15 @@ static uint32_t trace_chunk(const jade_scene* s, uint32_t n_rays) {
 
 static hipError_t sum_counters(jade_scene* s, DevCounters* out) {
   std::vector<DevCounters> sh(JADE_CTR_SHARDS);
-  hipError_t e = hipMemcpy(sh.data(), s->b_ctr.p, sizeof(DevCounters) * JADE_CTR_SHARDS, hipMemcpyDeviceToHost);
+  hipError_t e = hipMemcpyAsync(sh.data(), s->b_ctr.p, sizeof(DevCounters) * JADE_CTR_SHARDS, hipMemcpyDeviceToHost, s->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
   memset(out, 0, sizeof *out);
   for (const DevCounters& c : sh) {
-    out->rays_primary += c.rays_primary; out->rays_secondary += c.rays_secondary;
+    out->rays_primary += c.rays_primary; out->rays_shadow += c.rays_shadow;
     out->nodes_visited += c.nodes_visited; out->tris_tested += c.tris_tested;
     out->shaded_hits += c.shaded_hits; out->samples += c.samples;
+    out->rays_env += c.rays_env; out->rays_indirect += c.rays_indirect;
+    out->rays_mirror += c.rays_mirror; out->rays_refract += c.rays_refract;
     out->pad[0] += c.pad[0]; out->pad[1] += c.pad[1];
   }
 #if JADE_TRACE_PROFILE
@@ -1012,6 +1058,7 @@ static int run_passes(jade_scene* s, uint32_t target_spp, bool may_carry, double
                      s->b_active[0].as<uint32_t>(), qc);
   HIP_TRY(hipMemcpyAsync(host_ctl, qc, 12, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  s->host_syncs += 1;
   uint32_t n_active = host_ctl[1];
   const uint32_t n_armed = n_active;  // records with work at the start of this call
   int cur = 0, pass_no = 0;
@@ -1056,6 +1103,7 @@ static int run_passes(jade_scene* s, uint32_t target_spp, bool may_carry, double
     if (log_passes) HIP_TRY(hipEventRecord(sb, s->stream));
     HIP_TRY(hipMemcpyAsync(host_ctl, qc, 12, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
+  s->host_syncs += 1;
     if (log_passes) {
       HIP_TRY(hipEventElapsedTime(&shade_ms, sa, sb));
       HIP_TRY(hipEventElapsedTime(&lean_ms, sa, sm));
@@ -1102,6 +1150,7 @@ static int run_passes(jade_scene* s, uint32_t target_spp, bool may_carry, double
   }
   HIP_TRY(hipEventRecord(ev1, s->stream));
   HIP_TRY(hipEventSynchronize(ev1));
+  s->host_syncs += 1;
   float ms = 0;
   HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
   *ms_out = ms;
@@ -1132,7 +1181,12 @@ static int advance(jade_scene* s, int64_t from0, bool may_carry, jade_stats* st)
     DevCounters c{};
     HIP_TRY(sum_counters(s, &c));
     st->rays_primary += c.rays_primary;
-    st->rays_secondary += c.rays_secondary;
+    st->rays_secondary += c.rays_shadow + c.rays_env + c.rays_indirect + c.rays_mirror + c.rays_refract;
+    st->rays_shadow += c.rays_shadow;
+    st->rays_env += c.rays_env;
+    st->rays_indirect += c.rays_indirect;
+    st->rays_mirror += c.rays_mirror;
+    st->rays_refract += c.rays_refract;
     st->nodes_visited += c.nodes_visited;
     st->tris_tested += c.tris_tested;
     st->shaded_hits += c.shaded_hits;
@@ -1140,7 +1194,9 @@ static int advance(jade_scene* s, int64_t from0, bool may_carry, jade_stats* st)
     st->kernel_ms += ms;
     st->trace_ms += trace_ms;
     st->trace_launches += launches;
+    st->host_syncs += s->host_syncs;
   }
+  s->host_syncs = 0;
   return JADE_OK;
 }
 
@@ -1217,7 +1273,13 @@ int jade_render_resolve_tiles_device(jade_scene* s, float* dev_tiles, void* stre
   HIP_TRY(hipSetDevice(s->device));
   if (int rc = jade_render_flush(s, nullptr)) return rc;
   HIP_TRY(hipStreamSynchronize(s->stream));
-  return resolve_to(s, JADE_TONEMAP_ACES, 0.0f, dev_tiles, nullptr, (hipStream_t)stream);
+  if (int rc = resolve_to(s, JADE_TONEMAP_ACES, 0.0f, dev_tiles, nullptr, (hipStream_t)stream)) return rc;
+  // k_resolve reads the partial sums on the CALLER's stream: the scene's own stream must not start the next
+  // step (which adds to them) before it has finished
+  if (!s->ev_resolve) HIP_TRY(hipEventCreateWithFlags(&s->ev_resolve, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(s->ev_resolve, (hipStream_t)stream));
+  HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_resolve, 0));
+  return JADE_OK;
 }
 
 int jade_render(jade_scene* s, const jade_render_params* rp, float* out_rgb, uint8_t* out_bgr8, jade_stats* st) {
@@ -1336,6 +1398,8 @@ int jade_render_multi(jade_scene* const* scenes, int ndev, const jade_render_par
   if (st)
     for (int i = 0; i < ndev; ++i) {
       st->rays_primary += sts[i].rays_primary; st->rays_secondary += sts[i].rays_secondary;
+      st->rays_shadow += sts[i].rays_shadow; st->rays_env += sts[i].rays_env; st->rays_indirect += sts[i].rays_indirect;
+      st->rays_mirror += sts[i].rays_mirror; st->rays_refract += sts[i].rays_refract; st->host_syncs += sts[i].host_syncs;
       st->nodes_visited += sts[i].nodes_visited; st->tris_tested += sts[i].tris_tested;
       st->shaded_hits += sts[i].shaded_hits; st->samples += sts[i].samples;
       st->kernel_ms = std::max(st->kernel_ms, sts[i].kernel_ms);  // the shares run concurrently
@@ -1358,54 +1422,52 @@ int jade_trace_rays(jade_scene* s, int32_t n, const float* origins, const float*
   std::vector<uint32_t> q(N);
   for (size_t i = 0; i < N; ++i) q[i] = (uint32_t)i;
   DevBuf b_org, b_dir, b_skip, b_hit, b_hpt, b_q, b_spill;
-  HIP_TRY(upload(b_org, so.data(), so.size()));
-  HIP_TRY(upload(b_dir, sd.data(), sd.size()));
+  HIP_TRY(upload(b_org, so.data(), so.size(), s->stream));
+  HIP_TRY(upload(b_dir, sd.data(), sd.size(), s->stream));
   std::vector<int32_t> sk(skip, skip + N);
   for (int32_t& v : sk)
     if (v < 0) v = -1;  // any negative value means "no source triangle" (the device keeps -2 for camera rays)
-  HIP_TRY(upload(b_skip, sk.data(), N));
+  HIP_TRY(upload(b_skip, sk.data(), N, s->stream));
+  DevBuf b_hdist;
   HIP_TRY(b_hit.alloc(N * 4));
   HIP_TRY(b_hpt.alloc(3 * N * 4));
-  HIP_TRY(upload(b_q, q.data(), N));
+  HIP_TRY(b_hdist.alloc(N * 4));
+  HIP_TRY(hipMemsetAsync(b_hpt.p, 0, 3 * N * 4, s->stream));  // the hit point of a miss is never written: report zeros
+  HIP_TRY(upload(b_q, q.data(), N, s->stream));
   HIP_TRY(b_spill.alloc((size_t)(JADE_BVH_STACK_CAPACITY - JADE_LDS_STACK) * s->trace_blocks * JADE_TRACE_BLOCK * 4));
   PathState P{};
   P.npix = n;
   P.nslots = 1;
   P.org = b_org.as<float>(); P.dir = b_dir.as<float>(); P.skip = b_skip.as<int32_t>();
-  P.hit = b_hit.as<int32_t>(); P.hpt = b_hpt.as<float>();
+  P.hit = b_hit.as<int32_t>(); P.hpt = b_hpt.as<float>(); P.hdist = b_hdist.as<float>();
+  // everything on the scene's own (non-blocking) stream: the null stream does not order against it
   QueueCtl qc{};
   qc.count = (uint32_t)n;
-  HIP_TRY(hipMemcpy(s->b_ctl.p, &qc, 12, hipMemcpyHostToDevice));  // count, active, next
-  HIP_TRY(hipMemset(s->b_ctr.p, 0, sizeof(DevCounters) * JADE_CTR_SHARDS));
-  hipEvent_t ev0, ev1;
-  HIP_TRY(hipEventCreate(&ev0));
-  HIP_TRY(hipEventCreate(&ev1));
-  HIP_TRY(hipEventRecord(ev0, s->stream));
+  HIP_TRY(hipMemcpyAsync(s->b_ctl.p, &qc, 12, hipMemcpyHostToDevice, s->stream));  // count, active, next
+  HIP_TRY(hipMemsetAsync(s->b_ctr.p, 0, sizeof(DevCounters) * JADE_CTR_SHARDS, s->stream));
+  DevEvent ev0, ev1;
+  HIP_TRY(ev0.create());
+  HIP_TRY(ev1.create());
+  HIP_TRY(hipEventRecord(ev0.e, s->stream));
   hipLaunchKernelGGL(k_trace, dim3((unsigned)s->trace_blocks), dim3(JADE_TRACE_BLOCK), 0, s->stream, s->dev, P, b_q.as<uint32_t>(),
                      s->b_ctl.as<QueueCtl>(), b_spill.as<uint32_t>(), s->b_ctr.as<DevCounters>(), trace_chunk(s, (uint32_t)n));
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(ev1, s->stream));
-  HIP_TRY(hipEventSynchronize(ev1));
+  HIP_TRY(hipEventRecord(ev1.e, s->stream));
+  HIP_TRY(hipEventSynchronize(ev1.e));
   float ms = 0;
-  HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
-  (void)hipEventDestroy(ev0);
-  (void)hipEventDestroy(ev1);
+  HIP_TRY(hipEventElapsedTime(&ms, ev0.e, ev1.e));
   std::vector<float> hp(3 * N);
-  HIP_TRY(hipMemcpy(hit_index, b_hit.p, N * 4, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(hp.data(), b_hpt.p, 3 * N * 4, hipMemcpyDeviceToHost));
-  for (size_t i = 0; i < N; ++i) {
-    float px = hp[i], py = hp[N + i], pz = hp[2 * N + i];
-    if (hit_point) { hit_point[3 * i] = px; hit_point[3 * i + 1] = py; hit_point[3 * i + 2] = pz; }
-    if (hit_dist) {
-      // HitResult.distance = dot(P - o, normalize(d)), PathTrace.cu:740; recomputed with the shared helpers
-      if (hit_index[i] < 0) hit_dist[i] = JADE_INF_F;
-      else {
-        jvec3 o = jv(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]);
-        jvec3 dn = jv_normalize(jv(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]));
-        hit_dist[i] = jv_dot(jv_sub(jv(px, py, pz), o), dn);
-      }
+  HIP_TRY(hipMemcpyAsync(hit_index, b_hit.p, N * 4, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipMemcpyAsync(hp.data(), b_hpt.p, 3 * N * 4, hipMemcpyDeviceToHost, s->stream));
+  // HitResult.distance (PathTrace.cu:740) exactly as the kernel compared it (hitArray's `<`, :787); a miss keeps INF (:799)
+  if (hit_dist) HIP_TRY(hipMemcpyAsync(hit_dist, b_hdist.p, N * 4, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  if (hit_point)
+    for (size_t i = 0; i < N; ++i) {
+      hit_point[3 * i] = hp[i];
+      hit_point[3 * i + 1] = hp[N + i];
+      hit_point[3 * i + 2] = hp[2 * N + i];
     }
-  }
   if (st) {
     DevCounters c{};
     HIP_TRY(sum_counters(s, &c));

@@ -136,7 +136,8 @@ struct ShadeCtx {
   // what this pass emits
   int n_emit_rays;  // number of active slots written
   // counters
-  uint32_t c_primary, c_secondary, c_shaded, c_samples;
+  uint32_t c_primary, c_shadow, c_shaded, c_samples;
+  uint32_t c_cls;  // rays emitted by call site, one byte each: env | indirect << 8 | mirror << 16 | refract << 24 (a record emits once per pass)
 };
 
 // push (dir, rate) — forward form of stack_dir / stack_indir_rate.  Returns

@@ -145,8 +145,11 @@ int main(int argc, char** argv) {
   if (api.render(dev, &rp, rgb.data(), bgr.data(), &st) != JADE_OK) { fprintf(stderr, "render: %s\n", api.last_error()); return 1; }
   api.scene_destroy(dev);
   double rays = (double)(st.rays_primary + st.rays_secondary);
-  printf("{\"rays\": %.0f, \"kernel_ms\": %.3f, \"mray_per_s\": %.3f, \"nodes_visited\": %llu, \"tris_tested\": %llu}\n", rays,
-         st.kernel_ms, rays / st.kernel_ms / 1e3, (unsigned long long)st.nodes_visited, (unsigned long long)st.tris_tested);
+  printf("{\"rays\": %.0f, \"kernel_ms\": %.3f, \"mray_per_s\": %.3f, \"rays_primary\": %llu, \"rays_secondary\": %llu, "
+         "\"nodes_visited\": %llu, \"tris_tested\": %llu, \"shaded_hits\": %llu, \"samples\": %llu}\n",
+         rays, st.kernel_ms, rays / st.kernel_ms / 1e3, (unsigned long long)st.rays_primary, (unsigned long long)st.rays_secondary,
+         (unsigned long long)st.nodes_visited, (unsigned long long)st.tris_tested, (unsigned long long)st.shaded_hits,
+         (unsigned long long)st.samples);
   bool ok;
   size_t dot = out.find_last_of('.');
   std::string ext = dot == std::string::npos ? "" : out.substr(dot);

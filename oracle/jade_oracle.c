@@ -74,6 +74,7 @@ struct jade_scene {
 
 typedef struct {
   uint64_t rays_primary, rays_secondary, nodes_visited, tris_tested, shaded_hits, samples;
+  uint64_t rays_shadow, rays_env, rays_indirect, rays_mirror, rays_refract; /* rays_secondary by hitBVH call site */
 } counters;
 
 typedef struct {
@@ -398,7 +399,7 @@ static jvec3 path_tracing(const jade_scene* s, HitResult hit, jvec3 direction, u
             Ray new_ray;
             new_ray.startPoint = ray_src;
             new_ray.direction = obj_light_direction;
-            c->rays_secondary++;
+            c->rays_secondary++; c->rays_shadow++;
             HitResult hit_result = hit_bvh(s, new_ray, obj_hit.index, c);
             if (hit_result.isHit && hit_result.index == emit_tri_idx) {
               float dls = jv_dot(obj_light_direction, obj_light_direction);
@@ -417,7 +418,7 @@ static jvec3 path_tracing(const jade_scene* s, HitResult hit, jvec3 direction, u
             Ray new_ray;
             new_ray.startPoint = ray_src;
             new_ray.direction = ray_direction;
-            c->rays_secondary++;
+            c->rays_secondary++; c->rays_env++;
             HitResult hit_result = hit_bvh(s, new_ray, obj_hit.index, c);
             if (!hit_result.isHit) {
               jvec3 skyColor = sample_hdr(s, ray_direction);
@@ -437,7 +438,7 @@ static jvec3 path_tracing(const jade_scene* s, HitResult hit, jvec3 direction, u
             Ray new_ray;
             new_ray.startPoint = ray_src;
             new_ray.direction = ray_direction;
-            c->rays_secondary++;
+            c->rays_secondary++; c->rays_indirect++;
             HitResult new_hit = hit_bvh(s, new_ray, obj_hit.index, c);
             if (new_hit.isHit && nonemissive(&T[new_hit.index])) {
               ray_direction = jv_neg(ray_direction);
@@ -516,7 +517,7 @@ static jvec3 path_tracing(const jade_scene* s, HitResult hit, jvec3 direction, u
             Ray new_ray;
             new_ray.startPoint = random_point;
             new_ray.direction = obj_light_direction;
-            c->rays_secondary++;
+            c->rays_secondary++; c->rays_shadow++;
             HitResult hit_result = hit_bvh(s, new_ray, middle, c);
             if (hit_result.isHit && hit_result.index == emit_tri_idx) {
               float one_cosine_o = 1 - jade_fabs(jv_dot(jv_normalize(obj_light_direction), t_norm));
@@ -540,7 +541,7 @@ static jvec3 path_tracing(const jade_scene* s, HitResult hit, jvec3 direction, u
           Ray new_ray;
           new_ray.startPoint = random_point;
           new_ray.direction = ray_direction;
-          c->rays_secondary++;
+          c->rays_secondary++; c->rays_env++;
           HitResult hit_result = hit_bvh(s, new_ray, middle, c);
           if (!hit_result.isHit) {
             float one_cosine_o = 1 - jade_fabs(jv_dot(ray_direction, t_norm));
@@ -560,7 +561,7 @@ static jvec3 path_tracing(const jade_scene* s, HitResult hit, jvec3 direction, u
           if (rr_result < RR_F) {
             new_ray.startPoint = random_point;
             new_ray.direction = ray_direction;
-            c->rays_secondary++;
+            c->rays_secondary++; c->rays_indirect++;
             HitResult new_hit = hit_bvh(s, new_ray, middle, c);
             if (new_hit.isHit && nonemissive(&T[new_hit.index])) {
               ray_direction = jv_neg(ray_direction);
@@ -604,7 +605,7 @@ static jvec3 path_tracing(const jade_scene* s, HitResult hit, jvec3 direction, u
         new_ray.direction = refract_ray;
         HitResult new_hit = obj_hit;
         for (int i = 0; i < JADE_MAX_FULL_REFLEX_TIME; ++i) {
-          c->rays_secondary++;
+          c->rays_secondary++; c->rays_refract++;
           new_hit = hit_bvh(s, new_ray, new_hit.index, c);
           if (new_hit.isHit) {
             const jade_triangle* ht = &T[new_hit.index];
@@ -637,7 +638,7 @@ static jvec3 path_tracing(const jade_scene* s, HitResult hit, jvec3 direction, u
         float rr_result = jade_rand(rng);
         if (rr_result < RR_F) {
           new_ray.direction = refract_ray;
-          c->rays_secondary++;
+          c->rays_secondary++; c->rays_refract++;
           new_hit = hit_bvh(s, new_ray, new_hit.index, c);
           if (new_hit.isHit) {
             out_direction = jv_scale(refract_ray, -1.0f);
@@ -674,7 +675,7 @@ static jvec3 path_tracing(const jade_scene* s, HitResult hit, jvec3 direction, u
           Ray new_ray;
           new_ray.startPoint = ray_src;
           new_ray.direction = obj_light_direction;
-          c->rays_secondary++;
+          c->rays_secondary++; c->rays_shadow++;
           HitResult hit_result = hit_bvh(s, new_ray, obj_hit.index, c);
           if (hit_result.isHit && hit_result.index == emit_tri_idx) {
             float dls = jv_dot(obj_light_direction, obj_light_direction);
@@ -693,7 +694,7 @@ static jvec3 path_tracing(const jade_scene* s, HitResult hit, jvec3 direction, u
           Ray new_ray;
           new_ray.startPoint = ray_src;
           new_ray.direction = ray_direction;
-          c->rays_secondary++;
+          c->rays_secondary++; c->rays_env++;
           HitResult hit_result = hit_bvh(s, new_ray, obj_hit.index, c);
           if (!hit_result.isHit) {
             jvec3 skyColor = sample_hdr(s, ray_direction);
@@ -713,7 +714,7 @@ static jvec3 path_tracing(const jade_scene* s, HitResult hit, jvec3 direction, u
           Ray new_ray;
           new_ray.startPoint = ray_src;
           new_ray.direction = ray_direction;
-          c->rays_secondary++;
+          c->rays_secondary++; c->rays_indirect++;
           HitResult new_hit = hit_bvh(s, new_ray, obj_hit.index, c);
           if (new_hit.isHit && nonemissive(&T[new_hit.index])) {
             ray_direction = jv_neg(ray_direction);
@@ -743,7 +744,7 @@ static jvec3 path_tracing(const jade_scene* s, HitResult hit, jvec3 direction, u
             Ray new_ray;
             new_ray.startPoint = ray_src;
             new_ray.direction = out_direction;
-            c->rays_secondary++;
+            c->rays_secondary++; c->rays_mirror++;
             HitResult new_hit = hit_bvh(s, new_ray, obj_hit.index, c);
             float k = (float)(reflex_refract_select_rate / (JADE_RR_RATE_D / JADE_PI_D));
             if (new_hit.isHit) {
@@ -995,6 +996,11 @@ static void add_counters(jade_stats* st, const counters* c) {
   st->tris_tested += c->tris_tested;
   st->shaded_hits += c->shaded_hits;
   st->samples += c->samples;
+  st->rays_shadow += c->rays_shadow;
+  st->rays_env += c->rays_env;
+  st->rays_indirect += c->rays_indirect;
+  st->rays_mirror += c->rays_mirror;
+  st->rays_refract += c->rays_refract;
 }
 
 int jade_render_step(jade_scene* s, int32_t spp, jade_stats* st) {

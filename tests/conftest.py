@@ -66,7 +66,8 @@ def rel_l2(a, b):
     return float(np.sqrt(((a - b) ** 2).sum()) / max(np.sqrt((b ** 2).sum()), 1e-300))
 
 
-COUNTER_KEYS = ("rays_primary", "rays_secondary", "nodes_visited", "tris_tested", "shaded_hits", "samples")
+COUNTER_KEYS = ("rays_primary", "rays_secondary", "nodes_visited", "tris_tested", "shaded_hits", "samples",
+                "rays_shadow", "rays_env", "rays_indirect", "rays_mirror", "rays_refract")
 
 
 def counters(st):
@@ -81,8 +82,8 @@ def fpm():
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, "libfpmath_test.so")
     src = os.path.join(ROOT, "tests", "native", "fpmath_export.c")
-    hdr = os.path.join(ROOT, "include", "jade_fpmath.h")
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    hdrs = [os.path.join(ROOT, "include", h) for h in ("jade_fpmath.h", "jade_rt.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in [src] + hdrs):
         subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", "-fno-fast-math",
                                "-I", os.path.join(ROOT, "include"), "-o", so, src])
     lib = ctypes.CDLL(so)

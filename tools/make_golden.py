@@ -35,7 +35,8 @@ def main():
             d = rng.normal(size=(256, 3)).astype(np.float32)
             skip = rng.integers(-1, hs.n_triangles, 256).astype(np.int32)
             ti, td, tp, tst = sc.trace_rays(o, d, skip)
-        ctr = np.array([st.rays_primary, st.rays_secondary, st.nodes_visited, st.tris_tested, st.shaded_hits, st.samples], np.uint64)
+        ctr = np.array([st.rays_primary, st.rays_secondary, st.nodes_visited, st.tris_tested, st.shaded_hits, st.samples,
+                        st.rays_shadow, st.rays_env, st.rays_indirect, st.rays_mirror, st.rays_refract], np.uint64)
         hs.save_npz(os.path.join(out_dir, name + ".npz"), rgb=rgb, bgr8=bgr, counters=ctr,
                     params=np.array([p.width, p.height, p.spp, p.frame], np.int64), eye=np.array(p.eye[:], np.float32),
                     camera=np.array(p.camera[:], np.float32), ray_o=o, ray_d=d, ray_skip=skip, ray_hit=ti, ray_dist=td,

@@ -1,0 +1,41 @@
+#!/bin/bash
+# GPU box: the round-2 measurement set behind profiles/<tag>_*.
+#   1. the default bench run                               -> bench.json
+#   2. the same command under rocprofv3 --kernel-trace --stats
+#   3. one rocprofv3 --pmc pass per counter group over the SAME default command (no CPU baseline):
+#      SQ issue counters (the VALU roofline), FETCH_SIZE, WRITE_SIZE, L2 hits
+#   4. (with C5 as 2nd argument) kernel stats + the same counter groups for --config C5, where the
+#      geometry leaves the per-XCD L2
+# usage: tools/profile_r02.sh <tag> [C5]      then: tools/summarize_r02.py <tag>
+set -e
+R=${GRAFT_REPO_ROOT:-/root/repo}
+tag=$1
+O=$R/gpurun_out/$tag
+rm -rf $O
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+SQ="SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU"
+timeout -k 10 600 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
+tail -c 400 $O/bench.json; echo
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --no-cpu-baseline > $O/bench_profiled.json 2> $O/stats.log
+echo "stats done"
+i=0
+for grp in "$SQ" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+  i=$((i+1))
+  timeout -k 10 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/pmc_g$i -- python3 $R/bench.py --no-cpu-baseline > $O/pmc_g$i.log 2>&1 || echo "pmc group $i failed"
+  echo "pmc group $i done"
+done
+if [ "$2" = "C5" ]; then
+  C5ARGS="--config C5 --steps 2 --warmup 1 --spp-per-step 64 --no-cpu-baseline"
+  timeout -k 10 600 python3 $R/bench.py $C5ARGS > $O/c5_bench.json 2> $O/c5_bench.err
+  tail -c 300 $O/c5_bench.json; echo
+  timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5_stats -- python3 $R/bench.py $C5ARGS > $O/c5_bench_profiled.json 2> $O/c5_stats.log
+  i=0
+  for grp in "$SQ" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+    i=$((i+1))
+    timeout -k 10 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/c5_pmc_g$i -- python3 $R/bench.py $C5ARGS > $O/c5_pmc_g$i.log 2>&1 || echo "c5 pmc group $i failed"
+    echo "c5 pmc group $i done"
+  done
+fi
+# keep the merge-back small: the per-dispatch CSVs are reduced on the box
+python3 $R/tools/summarize_r02.py $tag --reduce-only || echo "reduce failed"
