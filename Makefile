@@ -8,8 +8,8 @@ CXX      ?= g++
 # -ffp-contract=off everywhere: include/jade_fpmath.h pins the evaluation order.
 FPFLAGS  := -ffp-contract=off -fno-fast-math
 CXXFLAGS := -O2 -g -std=c++17 -fPIC -mfma $(FPFLAGS) -Wall -Wextra -Wno-unused-parameter -I$(ROOT)/include -I$(PKG)/host
-# -fno-slp-vectorize: packed fp32 pairs (v_pk_*_f32) need aligned register pairs and copies; without them
-# k_trace fits 60 VGPRs (8 waves/SIMD) instead of 70, and the kernel is latency-bound, not VALU-bound.
+# -fno-slp-vectorize: the compiler's own packing of fp32 pairs (v_pk_*_f32) needs aligned register pairs and copies
+# (+10...30 VGPRs, measured slower); the packed operations k_trace does use are written by hand (jade_trace.h).
 HIPVEC   ?= -fno-slp-vectorize
 HIPFLAGS := $(HIPDEFS) -O3 $(HIPVEC) -std=c++17 -fPIC --offload-arch=gfx950 $(FPFLAGS) -fhip-fp32-correctly-rounded-divide-sqrt \
             -fno-gpu-flush-denormals-to-zero -mfma -Wall -Wno-unused-parameter -I$(ROOT)/include -I$(PKG)/csrc
@@ -43,6 +43,11 @@ $(LIBDIR)/libjade_hip_stack4.so: $(HIP_SRC) $(HIP_HDR)
 
 hipvariants: $(LIBDIR)/libjade_hip_stack4.so
 
+# development A/B builds (tools/ab_variants.py): make variant NAME=_b256 DEFS="-DJADE_TRACE_BLOCK=256 -DJADE_LDS_TOP_NODES=0"
+variant: $(HIP_SRC) $(HIP_HDR)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(DEFS) $(HIPFLAGS) -shared -o $(LIBDIR)/libjade_hip$(NAME).so $(HIP_SRC)
+
 $(LIBDIR)/jade_render: $(PKG)/host/jade_render_cli.cpp $(LIBDIR)/libjade_host.so $(HOST_HDR)
 	$(CXX) $(CXXFLAGS) -o $@ $(PKG)/host/jade_render_cli.cpp -L$(LIBDIR) -ljade_host -ldl -Wl,-rpath,'$$ORIGIN'
 
@@ -63,4 +68,4 @@ clean:
 	rm -rf $(LIBDIR)
 	$(MAKE) -C $(ROOT)/oracle clean
 
-.PHONY: all host hip hipvariants oracle cli clean asan-check
+.PHONY: all host hip hipvariants variant oracle cli clean asan-check

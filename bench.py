@@ -1,46 +1,53 @@
 #!/usr/bin/env python3
 """bench.py — Mray/s of the jade path-tracing hot path on MI355X.
 
-Contract (driver): python bench.py --gpus N --steps K --warmup W ; for N > 1 it is
-launched by torch.distributed.run, one rank per GPU (RCCL).  One JSON line on rank 0.
+Contract (driver): python bench.py --gpus N --steps K --warmup W ; for N > 1 the driver launches it with
+torch.distributed.run, one rank per GPU (RCCL).  Started by hand with --gpus N > 1 and no launcher, it starts
+that launcher itself as a child process — before anything touches the GPU — and exits with its code.  One JSON
+line on rank 0.
 
-Workload (BASELINE.json configs[2]/[3]): the 70k-triangle jade statue scene at
-1920x1080.  A "step" is one pass of the hot path adding `spp_per_step` samples to
-every pixel this rank owns; the per-pixel RNG streams and radiance sums stay on
-the GPU between steps, so K steps are K*spp_per_step samples of the same
-render, not K restarts; the defaults (4 steps x 1024 spp) are exactly the
-4096-spp render BASELINE.json names.  Multi-GPU: the image's 16x16 tiles are dealt
-round-robin to the ranks and the samples per step scale with N, so per-GPU work
-per step is constant ("weak"); after the timed steps the framebuffer is
-collected with ONE gather (RCCL), timed separately as gather_ms.  A step may hand
-its last few unfinished paths to the next step (jade_render_flush, jade_rt.h); the
-warm-up is flushed before the clock starts and the K timed steps are flushed before
-it stops, so every sample of the K steps — `samples` = K * spp * pixels, and all
-their rays — is computed inside the timed region.
+Workload (BASELINE.json configs[2]/[3]): the 70k-triangle jade statue scene at 1920x1080.  A "step" is one pass of
+the hot path adding `spp_per_step` samples to every pixel this rank owns; the per-sample RNG streams and radiance
+sums stay on the GPU between steps, so K steps are K*spp_per_step samples of the same render, not K restarts; the
+defaults (4 steps x 1024 spp) are exactly the 4096-spp render BASELINE.json names.  Multi-GPU: the image's 16x16
+tiles are dealt (tx + ty) % N to the ranks and the samples per step scale with N, so per-GPU work per step is
+constant ("weak"); after the timed steps the framebuffer is collected with ONE gather (RCCL), timed separately as
+gather_ms.  A step may hand its last few unfinished paths to the next step (jade_render_flush, jade_rt.h); the
+warm-up is flushed before the clock starts and the K timed steps are flushed before it stops, so every sample of
+the K steps — `samples` = K * spp * pixels, and all their rays — is computed inside the timed region.
 
-value = (primary + secondary rays traced by all ranks in the K timed steps)
-        / max-over-ranks wall time, in Mray/s.  A ray = one hitBVH query.
-roofline: k_trace's algorithmic bytes (40 B per node record needed + 36 B per
-        triangle tested) / k_trace time measured with HIP events
-        on its own stream (jade_stats.trace_ms), against 8 TB/s HBM.  The bytes are
-        algorithmic: the scene is L2-resident, `traffic` (HBM bytes per launch from
-        profiles/hbm_traffic.json, PMC) is what HBM really moves.
-cpu_baseline: the CPU oracle ("port": the reference has no CPU integrator) on a
-        bounded sample of the same scene, rank 0 at N = 1 only.
+value = (primary + secondary rays traced by all ranks in the K timed steps) / max-over-ranks wall time, Mray/s.
+        A ray = one hitBVH query (PathTrace.cu:795).
+roofline: the dominant kernel, k_trace (BVH traversal + triangle tests), against the roof that BINDS it: VALU
+        issue.  achieved = VALU lane-operations per second = (lane-ops per ray, SQ_THREAD_CYCLES_VALU from the
+        rocprofv3 --pmc pass of this same command, profiles/valu_issue.json) x (rays this run traced) / (k_trace
+        time of this run, HIP events on the kernel's own stream); peak = 1024 SIMDs x 32 lanes x 2.4 GHz.  frac is
+        therefore (lanes active per VALU instruction / 64) x (share of cycles the VALU pipes issue), <= 1.
+roofline_hbm: the HBM view SURVEY.md 8d prices the path with.  achieved = MEASURED HBM bytes (PMC FETCH_SIZE x 2 +
+        WRITE_SIZE per ray, profiles/hbm_traffic.json) x rays / k_trace time, against 8 TB/s; `algorithmic_GBps` is
+        the reference traversal's 40 B per node record + 36 B per triangle test delivered per second — it exceeds
+        the HBM peak because the scene is L2-resident, which is why it is not a roofline.
+cpu_baseline: the CPU oracle ("port": the reference has no CPU integrator) on a bounded sample of the same scene,
+        rank 0 at N = 1 only.
+extras (N = 1): secondary rays by call site, and the same scene with the camera moved in until the statue fills
+        the frame (every pixel a jade path): the throughput on the rays the headline frame has few of.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s
+VALU_PEAK_TLANEOPS = 1024 * 32 * 2.4e9 / 1e12  # 256 CUs x 4 SIMD-32, one lane-op per lane per clock, 2.4 GHz = 78.6
 
 
-def main():
+def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
@@ -50,28 +57,51 @@ def main():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--bvh", default="sah", choices=["sah", "lbvh"],
-                    help="sah: the reference's host builder (default, what the metric is quoted on); lbvh: GPU builder")
+    ap.add_argument("--no-extras", action="store_true", help="skip the statue-filling camera variant")
+    ap.add_argument("--bvh", default="sah", choices=["sah", "lbvh", "ploc"],
+                    help="sah: the reference's host builder (default, what the metric is quoted on); lbvh / ploc: GPU builders")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL) for real runs; gloo rehearses the multi-rank flow with every rank on one GPU")
     ap.add_argument("--virtual-ranks", type=int, default=0,
                     help="development: render rank 0's share of a V-GPU run on this one GPU (partition and spp as at N=V)")
     ap.add_argument("--cpu-spp", type=int, default=8, help="oracle sample: spp over the full frame")
-    args = ap.parse_args()
+    return ap.parse_args()
 
+
+def spawn_ranks(n):
+    """--gpus N > 1 without a launcher: start torch.distributed.run as a CHILD process (never exec: a process that
+    has initialised the GPU must not be replaced, and this one has not touched it yet) and return its exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this host driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def profile_json(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return None
+
+
+def main():
+    args = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    if world == 1 and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
+    args.gpus = world
 
     import torch
     import torch.distributed as dist
 
     import jaderaytracerendering_amd as J
-    from jaderaytracerendering_amd import _abi, backend as B, distributed as D
+    from jaderaytracerendering_amd import _abi, backend as B, distributed as D, host as H
 
     hip = J.hip()  # raises if the HIP extension is missing: no fallback
     if not torch.cuda.is_available():
@@ -90,11 +120,11 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     t0 = time.time()
-    lbvh_ms = None
-    if args.bvh == "lbvh":
+    dev_build_ms = None
+    if args.bvh != "sah":
         sb = J.SceneBuilder()
         cfg = sb.config(args.config)
-        hs, lbvh_ms = sb.build_lbvh(hip, device_id=local_rank if args.dist_backend != "gloo" else 0)
+        hs, dev_build_ms = sb.build_device_bvh(hip, args.bvh, device_id=local_rank)
         sb.close()
     else:
         hs, cfg = J.build_config(args.config)
@@ -107,6 +137,8 @@ def main():
     spp_step = args.spp_per_step * part_world  # weak scaling: fixed work per GPU per step
     params = B.make_params(width, height, spp_step, list(cfg.eye), list(cfg.camera), tile_rank=part_rank,
                            tile_nranks=part_world, device_id=local_rank)
+    if rehearsal and world > 1:  # ranks share one GPU: each may hold its share of the memory, not 60 % of what is free
+        params.max_state_bytes = int(0.6 * torch.cuda.mem_get_info(local_rank)[0] / world)
     scene = hip.scene(hs, device_id=local_rank)
 
     def barrier():
@@ -144,8 +176,10 @@ def main():
     if rank == 0 and frame is not None:
         frame_ok = bool(torch.isfinite(frame).all().item()) and tuple(frame.shape) == (height, width, 3)
 
+    cls_keys = ("rays_primary", "rays_shadow", "rays_env", "rays_indirect", "rays_mirror", "rays_refract")
     vals = torch.tensor([float(st.rays_primary + st.rays_secondary), float(st.nodes_visited), float(st.tris_tested),
-                         st.trace_ms, float(st.trace_launches), float(st.samples)], dtype=torch.float64, device=cdev)
+                         st.trace_ms, float(st.trace_launches), float(st.samples)] + [float(getattr(st, k)) for k in cls_keys],
+                        dtype=torch.float64, device=cdev)
     tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(vals, op=dist.ReduceOp.SUM)
@@ -154,18 +188,41 @@ def main():
     rays_all = float(vals[0].item())
 
     if rank == 0:
-        # roofline of the dominant kernel (k_trace) on THIS rank
+        # rooflines of the dominant kernel (k_trace) on THIS rank
+        rays_rank = float(st.rays_primary + st.rays_secondary)
         alg_bytes = 40.0 * st.nodes_visited + 36.0 * st.tris_tested
         launches = max(int(st.trace_launches), 1)
         trace_s = st.trace_ms * 1e-3
-        achieved = alg_bytes / trace_s / 1e9 if trace_s > 0 else 0.0
-        traffic = None
-        prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(prof):
-            try:  # PMC: HBM bytes per algorithmic byte of k_trace (tools/summarize_pmc.py), per launch like `achieved`
-                traffic = json.load(open(prof)).get("k_trace_hbm_bytes_per_algorithmic_byte") * alg_bytes / launches
-            except Exception:
-                traffic = None
+        # per-ray counter figures exist for the configurations that were profiled (same scene, frame and BVH)
+        key = {"C3": "C3", "C4": "C3", "C5": "C5"}.get(args.config) if (args.bvh == "sah" and not args.width and not args.height) else None
+        valu = (profile_json("valu_issue.json") or {}).get(key)
+        hbm = (profile_json("hbm_traffic.json") or {}).get(key)
+        roof = {"bound": "valu", "kernel": "k_trace", "achieved": None, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s", "frac": None,
+                "traffic": None, "avg_launch_ms": st.trace_ms / launches, "launches": launches,
+                "trace_share_of_step_time": trace_s / (st.kernel_ms * 1e-3) if st.kernel_ms else None,
+                # what a profiler sees for the same command: every k_trace launch of the process, warm-up included
+                "launches_incl_warmup": launches + int(st_w.trace_launches),
+                "avg_launch_ms_incl_warmup": (st.trace_ms + st_w.trace_ms) / max(launches + int(st_w.trace_launches), 1),
+                "rays_per_launch": rays_rank / launches}
+        if valu and valu.get("valu_lane_ops_per_ray") and trace_s > 0:
+            ach = valu["valu_lane_ops_per_ray"] * rays_rank / trace_s / 1e12
+            roof.update({"achieved": ach, "frac": ach / VALU_PEAK_TLANEOPS, "valu_lane_ops_per_ray": valu["valu_lane_ops_per_ray"],
+                         "lanes_per_valu_inst_of_64": valu.get("lanes_per_valu_inst"), "valu_busy_profiled": valu.get("valu_busy"),
+                         "counters_from": valu.get("source"),
+                         "note": "lane-ops per ray from the rocprofv3 --pmc SQ pass of this command (tracked summary named in "
+                                 "counters_from); rays and k_trace time are this run's.  frac = share of the chip's VALU lane-cycles "
+                                 "that carry a lane of this kernel's work"})
+        roof_hbm = {"bound": "hbm", "kernel": "k_trace", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                    "algorithmic_GBps": alg_bytes / trace_s / 1e9 if trace_s > 0 else None,
+                    "algorithmic_bytes_per_launch": alg_bytes / launches,
+                    "algorithmic_bytes_per_ray": alg_bytes / rays_rank if rays_rank else None}
+        if hbm and hbm.get("k_trace_hbm_bytes_per_ray") and trace_s > 0:
+            b = hbm["k_trace_hbm_bytes_per_ray"] * rays_rank
+            roof_hbm.update({"achieved": b / trace_s / 1e9, "frac": b / trace_s / 1e9 / HBM_PEAK_GBS, "traffic": b / launches,
+                             "l2_hit_rate_profiled": hbm.get("k_trace_l2_hit_rate"), "counters_from": hbm.get("source"),
+                             "note": "measured HBM bytes (2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md) per ray from the --pmc passes "
+                                     "of this command; the BVH is cache-resident, so HBM sees the ray records, not the traversal"})
+            roof["traffic"] = b / launches
         out = {
             "metric": "Mray/s (primary+secondary)",
             "value": rays_all / dt / 1e6,
@@ -189,31 +246,53 @@ def main():
             "rehearsal_all_ranks_on_one_gpu": True if rehearsal else None,
             "rays": rays_all,
             "samples": float(vals[5].item()),
+            "rays_incl_warmup_this_rank": float(st.rays_primary + st.rays_secondary + st_w.rays_primary + st_w.rays_secondary),
+            "rays_by_call_site": {k[5:]: float(vals[6 + i].item()) for i, k in enumerate(cls_keys)},
             "gather_ms": gather_ms,
             "frame_ok": frame_ok,
+            "host_syncs_per_step": st.host_syncs / max(args.steps, 1),
             "scene_build_s": build_s,
-            "bvh": args.bvh, "lbvh_device_ms": lbvh_ms,
+            "bvh": args.bvh, "device_bvh_ms": dev_build_ms,
             "nodes_per_ray": float(vals[1].item()) / rays_all, "tris_per_ray": float(vals[2].item()) / rays_all,
-            "roofline": {
-                "bound": "hbm", "kernel": "k_trace", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "algorithmic_bytes_per_launch": alg_bytes / launches, "avg_launch_ms": st.trace_ms / launches,
-                "launches": launches, "trace_share_of_step_time": trace_s / (st.kernel_ms * 1e-3) if st.kernel_ms else None,
-                # what a profiler sees for the same command: every k_trace launch of the process, warm-up included
-                # (the warm-up closes with its own tail of small launches, so its average is lower)
-                "launches_incl_warmup": launches + int(st_w.trace_launches),
-                "avg_launch_ms_incl_warmup": (st.trace_ms + st_w.trace_ms) / max(launches + int(st_w.trace_launches), 1),
-                "note": "achieved counts the reference traversal's ALGORITHMIC bytes (SURVEY.md 8d); the scene is L2-resident, so "
-                        "traffic (HBM bytes per launch, PMC) is ~10x smaller and frac may exceed 1; PMC shows k_trace bound by VALU "
-                        "issue (profiles/r01_v7_sq_summary.json, DESIGN.md 3.4)",
-            },
+            "roofline": roof,
+            "roofline_hbm": roof_hbm,
         }
+        if world == 1 and part_world == 1 and not args.no_extras and args.config in ("C2", "C3", "C4"):
+            out["statue_closeup"] = closeup(scene, hip, B, H, _abi, cfg, width, height, args.spp_per_step)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(hs, cfg, width, height, args.cpu_spp)
         print(json.dumps(out), flush=True)
     scene.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def closeup(scene, hip, B, H, _abi, cfg, width, height, spp):
+    """The same scene with the camera moved in until the statue fills the frame: every pixel starts a jade path
+    (BSSRDF / SSS / mirror branches, ~4 shadow + environment + indirect rays per bounce).  The headline frame is
+    ~5 % statue; this is the rate on the rays it has few of.  One warm-up step, one timed step, both flushed."""
+    import numpy as np
+    hs = scene.host_scene
+    centre = hs.vertices()[hs.tri_i32()[:, 0] == 0].reshape(-1, 3).mean(0)  # object 0 is the statue (scene_io.cpp add_jade_scene)
+    forward = -np.array(cfg.camera[8:11], np.float32)                       # the view axis: M . (0, 0, -1, 0)
+    eye = centre - 0.22 * forward                                           # C3 looks at it from 0.56 away
+    spp = max(1, min(spp, 256))
+    p = B.make_params(width, height, spp, [float(x) for x in eye], list(cfg.camera))
+    scene.begin(p)
+    w = _abi.Stats()
+    scene.step(spp, w)
+    scene.flush(w)
+    st = _abi.Stats()
+    t0 = time.perf_counter()
+    scene.step(spp, st)
+    scene.flush(st)
+    dt = time.perf_counter() - t0
+    rays = float(st.rays_primary + st.rays_secondary)
+    return {"value": rays / dt / 1e6, "unit": "Mray/s", "spp": spp, "rays_per_sample": rays / max(st.samples, 1),
+            "nodes_per_ray": st.nodes_visited / rays, "tris_per_ray": st.tris_tested / rays,
+            "k_trace_Mray_per_s": rays / (st.trace_ms * 1e-3) / 1e6 if st.trace_ms else None,
+            "trace_share_of_step_time": st.trace_ms / st.kernel_ms if st.kernel_ms else None,
+            "camera": "C3's view direction, eye moved to 0.22 from the statue's centre (C3: 0.56)"}
 
 
 def usable_cores():

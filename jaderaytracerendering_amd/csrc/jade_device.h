@@ -43,8 +43,18 @@
 #define JADE_LDS_FIFO 4
 #endif
 /* leaf cursors waiting for their triangle tests, same LDS column (power of two) */
-#define JADE_LDS_STATE 8  /* ray-state words, same column (jade_trace.h): 20 words * 256 lanes = 20 KB/block, 8 blocks/CU */
+#define JADE_LDS_STATE 8  /* ray-state words, same column (jade_trace.h): 20 words per lane */
+// k_trace runs ONE 1024-thread workgroup per CU (4 waves/SIMD; 5 and 6 waves measured +6 % / +6 % at 256 threads, see
+// DESIGN.md): its lanes' columns take 80 KB of the CU's 160 KB of LDS and the rest holds the top of the BVH
+// (JADE_LDS_TOP_NODES node records, the ones with the largest boxes), staged once per launch.  PMC showed the kernel
+// bound by the vector-memory address/tag path (TA busy 79 %, 25 tag look-ups per wave load: every lane gathers its own
+// 64-B node record), with the LDS idle (7 %): node visits served from LDS never enter that path.
+#ifndef JADE_TRACE_BLOCK
 #define JADE_TRACE_BLOCK 256
+#endif
+#ifndef JADE_LDS_TOP_NODES  /* 0 = no staging (A/B builds) */
+#define JADE_LDS_TOP_NODES 96
+#endif
 #define JADE_RECORD_MEMORY 0.60 /* share of the free device memory that path records + partial sums may take: paths in \
                                   flight are what fills the wide passes (1080p on one GPU: 32 -> 256 records per pixel = +21 %) */
 
@@ -60,6 +70,7 @@ struct DevScene {
   int32_t env_w, env_h;
   int32_t n_tris, n_emit;
   uint32_t root_ref;
+  uint32_t top_k;             // internal nodes [0, top_k) are the ones k_trace stages in LDS (largest boxes first)
 };
 
 // Path records, structure of arrays.  Samples are independent work items

@@ -453,6 +453,16 @@ __global__ __launch_bounds__(JADE_LEAN_BLOCK) void k_shade_lean(DevScene S, Path
   shade_tail<true, JADE_LEAN_BLOCK / 64>(P, p, st, c, defer, nullptr, heavy_out, queue, qc, ctr);
 }
 
+#ifndef JADE_TRACE_NT
+#define JADE_TRACE_NT 1 /* k_trace reads and writes the ray records with non-temporal hints */
+#endif
+#if JADE_TRACE_NT
+#define NT_LD(p) __builtin_nontemporal_load(p)
+#define NT_ST(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define NT_LD(p) (*(p))
+#define NT_ST(p, v) (*(p) = (v))
+#endif
 #ifndef JADE_TRACE_PROFILE
 #define JADE_TRACE_PROFILE 0
 #endif
@@ -477,6 +487,18 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
   stk.lds = lds_cols + threadIdx.x;
   stk.spill = spill + gtid;
   stk.stride_spill = gridDim.x * blockDim.x;
+  stk.top = nullptr;
+  stk.top_k = 0;
+#if JADE_LDS_TOP_NODES > 0
+  __shared__ float4 lds_top[4 * JADE_LDS_TOP_NODES];
+  {  // stage the top of the tree: record i's j-th 16 bytes -> plane j, entry i (coalesced reads of S.nodes)
+    const uint32_t k = S.top_k;  // <= JADE_LDS_TOP_NODES (jade_scene_create)
+    for (uint32_t i = threadIdx.x; i < 4u * k; i += JADE_TRACE_BLOCK) lds_top[(i & 3u) * k + (i >> 2)] = S.nodes[i];
+    __syncthreads();
+    stk.top = lds_top;
+    stk.top_k = k;
+  }
+#endif
   const uint32_t n = qc->count;
   const int npix = P.npix;
   const size_t plane = (size_t)P.nslots * npix;
@@ -499,15 +521,17 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
     const int n_idle = __popcll(idle);
     if (n_idle >= JADE_REFILL_MIN) {
       if (wb) {
+        // ray records stream through once per pass: non-temporal, so that they do not push the BVH out of the XCD's
+        // 4 MB L2 (C3's node + vertex records are 4.1 MB; PMC: 124 of the 172 HBM bytes per ray were BVH lines re-fetched)
         const int32_t best = ray_best_index(stk);
-        P.hit[my_e] = best;
+        NT_ST(&P.hit[my_e], best);
         if (P.hdist) P.hdist[my_e] = lds_getf(stk, LW_BEST_DIST);  // wave-uniform: only jade_trace_rays asks for it
         if (best >= 0) {  // the hit point of a miss is never read
           const jvec3 hp = ray_hit_point(stk);
           float* hb = P.hpt + my_e;
-          hb[0] = hp.x;
-          hb[plane] = hp.y;
-          hb[2 * plane] = hp.z;
+          NT_ST(&hb[0], hp.x);
+          NT_ST(&hb[plane], hp.y);
+          NT_ST(&hb[2 * plane], hp.z);
         }
         wb = false;
       }
@@ -528,12 +552,13 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
         const uint32_t take = (uint32_t)n_idle < avail ? (uint32_t)n_idle : avail;
         const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
         if (!active && rank < take) {
-          my_e = queue[lbase + rank];
+          my_e = NT_LD(&queue[lbase + rank]);
           const uint32_t k = my_e / (uint32_t)npix, p = my_e - k * (uint32_t)npix;
-          const int32_t skip = P.skip[p];
-          const jvec3 o = skip == JADE_SKIP_CAMERA ? jv(P.eye[0], P.eye[1], P.eye[2]) : ld3(P.org, npix, p);
+          const int32_t skip = NT_LD(&P.skip[p]);
+          const jvec3 o = skip == JADE_SKIP_CAMERA ? jv(P.eye[0], P.eye[1], P.eye[2])
+                                                   : jv(NT_LD(&P.org[p]), NT_LD(&P.org[npix + p]), NT_LD(&P.org[2 * npix + p]));
           const float* db = P.dir + my_e;
-          const jvec3 d = jv(db[0], db[plane], db[2 * plane]);
+          const jvec3 d = jv(NT_LD(&db[0]), NT_LD(&db[plane]), NT_LD(&db[2 * plane]));
           ray_begin(r, stk, S, o, d, skip);
           active = true;
         }
@@ -798,12 +823,46 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
   if (device_id < 0 || device_id >= ndev) return fail(JADE_ERR_DEVICE, "no such HIP device");
   HIP_TRY(hipSetDevice(device_id));
 
-  // re-lay the BVH: compact the internal nodes, children's boxes in the parent
+  // re-lay the BVH: compact the internal nodes, children's boxes in the parent.  Internal nodes are numbered by
+  // decreasing surface area of their own box (the SAH's measure of how often a node is visited), so that any prefix
+  // [0, k) of the array is a connected top of the tree - a child's box is never larger than its parent's, ties keep
+  // the breadth-first order - and k_trace can keep that prefix in LDS (jade_device.h, JADE_LDS_TOP_NODES).
   const int nN = d->n_nodes;
   std::vector<int32_t> compact(nN, -1);
   int n_internal = 0;
-  for (int i = 1; i < nN; ++i)
-    if (d->nodes[i].n <= 0) compact[i] = n_internal++;
+  {
+    std::vector<int32_t> bfs;  // internal nodes reachable from the root, breadth first
+    bfs.reserve(nN);
+    if (d->nodes[1].n <= 0) bfs.push_back(1);
+    for (size_t h = 0; h < bfs.size(); ++h) {
+      const jade_bvh_node& nd = d->nodes[bfs[h]];
+      if (nd.left > 0 && d->nodes[nd.left].n <= 0) bfs.push_back(nd.left);
+      if (nd.right > 0 && d->nodes[nd.right].n <= 0) bfs.push_back(nd.right);
+    }
+    auto area = [&](int i) {
+      const jade_bvh_node& nd = d->nodes[i];
+      const double x = (double)nd.bb[0] - nd.aa[0], y = (double)nd.bb[1] - nd.aa[1], z = (double)nd.bb[2] - nd.aa[2];
+      return x * y + y * z + z * x;
+    };
+    std::vector<double> ar(bfs.size());
+    for (size_t h = 0; h < bfs.size(); ++h) ar[h] = area(bfs[h]);
+    // a child inherits at most its parent's key, so a prefix of the order is always closed under "parent of"
+    std::vector<double> key(nN, 0.0);
+    for (size_t h = 0; h < bfs.size(); ++h) {
+      const int i = bfs[h];
+      if (h == 0) key[i] = ar[0];
+      const jade_bvh_node& nd = d->nodes[i];
+      for (int ch : {nd.left, nd.right})
+        if (ch > 0 && d->nodes[ch].n <= 0) key[ch] = std::min(key[i], area(ch));
+    }
+    std::vector<int32_t> order(bfs.size());
+    for (size_t h = 0; h < bfs.size(); ++h) order[h] = (int32_t)h;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return key[bfs[a]] > key[bfs[b]]; });
+    for (int32_t h : order) compact[bfs[h]] = n_internal++;
+    // internal nodes the root does not reach (none in a valid tree) keep a slot so that every record exists
+    for (int i = 1; i < nN; ++i)
+      if (d->nodes[i].n <= 0 && compact[i] < 0) compact[i] = n_internal++;
+  }
   auto ref_of = [&](int child) -> uint32_t {
     if (child <= 0) return JADE_REF_NONE;
     const jade_bvh_node& c = d->nodes[child];
@@ -865,6 +924,7 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
   s->dev.n_tris = d->n_triangles;
   s->dev.n_emit = d->n_emit;
   s->dev.root_ref = ref_of(1);
+  s->dev.top_k = (uint32_t)std::min(n_internal, (int)JADE_LDS_TOP_NODES);
 
   // the arithmetic contract of jade_fpmath.h, checked on the device once
   hipLaunchKernelGGL(k_selftest, dim3(1), dim3(1), 0, s->stream, s->b_ctl.as<QueueCtl>(), 1.0f);
@@ -887,6 +947,10 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
   (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace, JADE_TRACE_BLOCK, 0);
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 8) per_cu = 8;
+  if (const char* e = getenv("JADE_TRACE_BLOCKS_PER_CU")) {  // development: occupancy sweeps (fewer resident blocks than fit)
+    const int v = atoi(e);
+    if (v >= 1 && v < per_cu) per_cu = v;
+  }
   if (getenv("JADE_LOG_PASSES")) fprintf(stderr, "[jade] k_trace: %d blocks of %d threads per CU, %d CUs\n", per_cu, JADE_TRACE_BLOCK, prop.multiProcessorCount);
   s->trace_blocks = prop.multiProcessorCount * per_cu;
   *out = s;

@@ -56,6 +56,8 @@ struct LdsStack {
   uint32_t* lds;       // base of this lane's column
   uint32_t* spill;     // global, spill[(level - JADE_LDS_STACK) * stride + gtid]
   uint32_t stride_spill;
+  const float4* top;   // LDS copy of node records [0, top_k): four planes of top_k float4 (plane j = the record's j-th 16 bytes)
+  uint32_t top_k;
 };
 enum {
   LW_FIFO = JADE_LDS_STACK,  // JADE_LDS_FIFO leaf cursors waiting for their triangle tests (ring)
@@ -74,8 +76,13 @@ static __device__ __forceinline__ void stack_push(const LdsStack& s, int sp, uin
   else s.spill[(size_t)(sp - JADE_LDS_STACK) * s.stride_spill] = v;
 }
 static __device__ __forceinline__ uint32_t stack_pop(const LdsStack& s, int sp) {
-  if (sp < JADE_LDS_STACK) return s.lds[sp * JADE_TRACE_BLOCK];
-  return s.spill[(size_t)(sp - JADE_LDS_STACK) * s.stride_spill];
+  // The LDS level is read unconditionally and made opaque: written as "LDS or global", the two loads become ONE flat
+  // load through a selected generic pointer, and every pop then travels the vector-memory address path (the unit
+  // k_trace is bound by) instead of being a plain ds_read.
+  uint32_t v = s.lds[(sp < JADE_LDS_STACK ? sp : 0) * JADE_TRACE_BLOCK];
+  asm volatile("" : "+v"(v));
+  if (sp >= JADE_LDS_STACK) v = s.spill[(size_t)(sp - JADE_LDS_STACK) * s.stride_spill];
+  return v;
 }
 
 // Two lanes of packed fp32 (v_pk_add/mul/fma_f32: full rate, IEEE per component, so the
@@ -330,9 +337,43 @@ static __device__ __forceinline__ void ray_step_node(RayState& r, const DevScene
     leafv = cur;
     need_pop = true;
   } else {
-    const float4* nd = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.nodes) + cur * 64u);
-    const float4 a = nd[0], b = nd[1], c = nd[2];
-    const uint2 rf = *reinterpret_cast<const uint2*>(nd + 3);
+    float4 a, b, c;
+    uint2 rf;
+#if JADE_LDS_TOP_NODES > 0
+    // The top of the tree lives in LDS, one plane per 16 bytes of the record (lane addresses 16 B apart spread over all
+    // 64 banks of a ds_read_b128); these visits - the most frequent ones - stay out of the vector-memory path.  Every
+    // lane reads LDS (a lane below the top reads entry 0: LDS bandwidth is idle) and only the lanes below the top issue
+    // global loads, into registers of their own: one `if` with both kinds of pointer in it makes the compiler fall back
+    // to per-dword FLAT loads for everything (12 loads per visit instead of 4).
+    const bool in_top = cur < stk.top_k;
+    const float4* t = stk.top + (in_top ? cur : 0u);
+    const float4 la = t[0], lb = t[stk.top_k], lc = t[2 * stk.top_k], lr = t[3 * stk.top_k];
+    float4 ga = la, gb = lb, gc = lc;
+    uint2 grf = make_uint2(jade_f2u(lr.x), jade_f2u(lr.y));
+    // (opaque to the optimiser, or it turns "LDS value, overwritten by a global load for some lanes" back into one load
+    // through a selected generic pointer)
+    asm volatile("" : "+v"(ga.x), "+v"(ga.y), "+v"(ga.z), "+v"(ga.w), "+v"(gb.x), "+v"(gb.y), "+v"(gb.z), "+v"(gb.w));
+    asm volatile("" : "+v"(gc.x), "+v"(gc.y), "+v"(gc.z), "+v"(gc.w), "+v"(grf.x), "+v"(grf.y));
+    if (!in_top) {
+      const float4* nd = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.nodes) + cur * 64u);
+      ga = nd[0];
+      gb = nd[1];
+      gc = nd[2];
+      grf = *reinterpret_cast<const uint2*>(nd + 3);
+    }
+    a = ga;
+    b = gb;
+    c = gc;
+    rf = grf;
+#else
+    {
+      const float4* nd = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.nodes) + cur * 64u);
+      a = nd[0];
+      b = nd[1];
+      c = nd[2];
+      rf = *reinterpret_cast<const uint2*>(nd + 3);
+    }
+#endif
     const jvec3 inv = jv(lds_getf(stk, LW_INVX), lds_getf(stk, LW_INVY), lds_getf(stk, LW_INVZ));
     const bool exact = (int32_t)r.skipx < 0;
     float d1 = -1.0f, d2 = -1.0f;

@@ -252,6 +252,12 @@ class SceneBuilder:
                                               len(nodes), C.byref(n_nodes), C.byref(ms)))
         return self.build_with_bvh(order, nodes[: n_nodes.value]), ms.value
 
+    def build_device_bvh(self, backend, kind="lbvh", leaf_size=8, device_id=0):
+        """(HostScene, device milliseconds) with the BVH built on the GPU: "lbvh" (Morton + Karras) or "ploc"."""
+        if kind == "lbvh":
+            return self.build_lbvh(backend, leaf_size, device_id)
+        raise ValueError(f"unknown device BVH builder {kind!r}")
+
     def build(self, leaf_size=8):
         h = self._lib.jadeh_builder_build(self._h, leaf_size)
         if not h:

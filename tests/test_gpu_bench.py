@@ -35,9 +35,14 @@ def test_bench_json_contract():
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
     assert d["value"] > 0 and d["frame_ok"] is True
-    rf = d["roofline"]
-    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["achieved"] > 0
+    rf, rh = d["roofline"], d["roofline_hbm"]
+    # the binding roof (VALU issue) and the HBM view; the per-ray counter figures exist for the profiled configurations
+    # (C3 / C5 at their own frame size) only, so a tiny run carries the live quantities and null for the rest
+    assert rf["bound"] == "valu" and rf["unit"] == "Tlane-op/s" and abs(rf["peak"] - 78.6432) < 1e-6 and rf["kernel"] == "k_trace"
+    assert rf["launches"] >= 1 and rf["avg_launch_ms"] > 0 and rf["achieved"] is None and rf["frac"] is None
+    assert rh["bound"] == "hbm" and rh["unit"] == "GB/s" and rh["peak"] == 8000.0 and rh["algorithmic_GBps"] > 0
+    assert set(d["rays_by_call_site"]) == {"primary", "shadow", "env", "indirect", "mirror", "refract"}
+    assert sum(d["rays_by_call_site"].values()) == d["rays"]
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "Mray/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
     # samples rendered in the timed region: 2 steps x 16 spp x 96 x 64 pixels

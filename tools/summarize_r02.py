@@ -113,7 +113,7 @@ def cut(pre, red, label, command):
             rl = b["roofline"]
             share = rl["launches"] / max(rl.get("launches_incl_warmup", rl["launches"]), 1)
             kt["note"] = "counters cover every launch of the process (warm-up included); per-ray figures use all rays of the process"
-            rays_all = b["rays"] / b["steps"] * (b["steps"] + b["warmup"])
+            rays_all = b.get("rays_incl_warmup_this_rank") or b["rays"] / b["steps"] * (b["steps"] + b["warmup"])
             kt["valu_lane_ops_per_ray"] = kt["lane_ops"] / rays_all
             kt["valu_wave_insts_per_ray"] = kt["SQ_INSTS_VALU"] / rays_all
             kt["timed_launch_share"] = share
@@ -142,7 +142,7 @@ def cut(pre, red, label, command):
             if b.get("roofline"):
                 rl = b["roofline"]
                 alg = rl["algorithmic_bytes_per_launch"] * rl["launches"] / rl.get("timed_launch_share_of_rays", 1.0)
-                rays_all = b["rays"] / b["steps"] * (b["steps"] + b["warmup"])
+                rays_all = b.get("rays_incl_warmup_this_rank") or b["rays"] / b["steps"] * (b["steps"] + b["warmup"])
                 summ["k_trace_hbm_bytes_per_ray"] = hbm / rays_all
                 summ["rays_of_profiled_process"] = rays_all
         for k in ("k_shade", "k_shade_lean"):
@@ -165,18 +165,28 @@ def main():
         return
     red = json.load(open(os.path.join(O, "reduced.json")))
     c3 = cut("", red, "C3", "--no-cpu-baseline")
-    cut("c5_", red, "C5", "--config C5 --steps 2 --warmup 1 --spp-per-step 64 --no-cpu-baseline")
+    c5 = cut("c5_", red, "C5", "--config C5 --steps 2 --warmup 1 --spp-per-step 64 --no-cpu-baseline")
     P = os.path.join(ROOT, "profiles")
-    if "sq" in c3 and "k_trace" in c3["sq"]["kernels"]:
-        kt = c3["sq"]["kernels"]["k_trace"]
-        json.dump({"source": "profiles/%s_sq_summary.json" % tag, "kernel": "k_trace",
-                   "valu_lane_ops_per_ray": kt.get("valu_lane_ops_per_ray"), "valu_wave_insts_per_ray": kt.get("valu_wave_insts_per_ray"),
-                   "lanes_per_valu_inst": kt["lanes_per_valu_inst"], "valu_busy": kt["valu_busy"]},
-                  open(os.path.join(P, "valu_issue.json"), "w"), indent=1)
-    if "pmc" in c3 and "k_trace_hbm_bytes_per_ray" in c3["pmc"]:
-        json.dump({"source": "profiles/%s_pmc_summary.json" % tag, "k_trace_hbm_bytes_per_ray": c3["pmc"]["k_trace_hbm_bytes_per_ray"],
-                   "k_trace_l2_hit_rate": c3["pmc"]["k_trace_l2_hit_rate"]},
-                  open(os.path.join(P, "hbm_traffic.json"), "w"), indent=1)
+
+    def load(name):
+        try:
+            d = json.load(open(os.path.join(P, name)))
+            return d if isinstance(d.get("C3", {}), dict) and "source" not in d else {}
+        except Exception:
+            return {}
+
+    valu, hbm = load("valu_issue.json"), load("hbm_traffic.json")
+    for key, pre, res in (("C3", "", c3), ("C5", "c5_", c5)):
+        if "sq" in res and "k_trace" in res["sq"]["kernels"]:
+            kt = res["sq"]["kernels"]["k_trace"]
+            valu[key] = {"source": "profiles/%s_%ssq_summary.json" % (tag, pre), "kernel": "k_trace",
+                         "valu_lane_ops_per_ray": kt.get("valu_lane_ops_per_ray"), "valu_wave_insts_per_ray": kt.get("valu_wave_insts_per_ray"),
+                         "lanes_per_valu_inst": kt["lanes_per_valu_inst"], "valu_busy": kt["valu_busy"]}
+        if "pmc" in res and "k_trace_hbm_bytes_per_ray" in res["pmc"]:
+            hbm[key] = {"source": "profiles/%s_%spmc_summary.json" % (tag, pre), "k_trace_hbm_bytes_per_ray": res["pmc"]["k_trace_hbm_bytes_per_ray"],
+                        "k_trace_l2_hit_rate": res["pmc"]["k_trace_l2_hit_rate"]}
+    json.dump(valu, open(os.path.join(P, "valu_issue.json"), "w"), indent=1)
+    json.dump(hbm, open(os.path.join(P, "hbm_traffic.json"), "w"), indent=1)
     print("wrote profiles/%s_*" % tag)
 
 
