@@ -33,20 +33,20 @@ $(LIBDIR)/libjade_host.so: $(HOST_SRC) $(HOST_HDR)
 
 $(LIBDIR)/libjade_hip.so: $(HIP_SRC) $(HIP_HDR)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC) -ldl
 
 # test-only build: a 4-entry LDS stack forces the global-memory spill path of the
 # traversal stack on every scene (tests/test_gpu_parity.py::test_stack_spill_path)
 $(LIBDIR)/libjade_hip_stack4.so: $(HIP_SRC) $(HIP_HDR)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) -DJADE_LDS_STACK=4 $(HIPFLAGS) -shared -o $@ $(HIP_SRC)
+	$(HIPCC) -DJADE_LDS_STACK=4 $(HIPFLAGS) -shared -o $@ $(HIP_SRC) -ldl
 
 hipvariants: $(LIBDIR)/libjade_hip_stack4.so
 
 # development A/B builds (tools/ab_variants.py): make variant NAME=_b256 DEFS="-DJADE_TRACE_BLOCK=256 -DJADE_LDS_TOP_NODES=0"
 variant: $(HIP_SRC) $(HIP_HDR)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(DEFS) $(HIPFLAGS) -shared -o $(LIBDIR)/libjade_hip$(NAME).so $(HIP_SRC)
+	$(HIPCC) $(DEFS) $(HIPFLAGS) -shared -o $(LIBDIR)/libjade_hip$(NAME).so $(HIP_SRC) -ldl
 
 $(LIBDIR)/jade_render: $(PKG)/host/jade_render_cli.cpp $(LIBDIR)/libjade_host.so $(HOST_HDR)
 	$(CXX) $(CXXFLAGS) -o $@ $(PKG)/host/jade_render_cli.cpp -L$(LIBDIR) -ljade_host -ldl -Wl,-rpath,'$$ORIGIN'

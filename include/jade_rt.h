@@ -231,11 +231,14 @@ int jade_owned_tile_count(int32_t width, int32_t height, int32_t tile_rank, int3
 /* One frame on several GPUs from ONE process.  scenes[i] must have been created
  * on the device that renders share i (jade_scene_create(desc, device_i, ..)); tiles are dealt
  * (tx + ty) % ndev exactly as with tile_rank / tile_nranks, every device renders its share
- * concurrently (one host thread per device), then device scenes[0] lives on collects the compact
- * tile buffers with peer-to-peer copies (xGMI) and the frame is assembled and tone-mapped once.
+ * concurrently (one host thread per device), then the device scenes[0] lives on collects the
+ * compact tile buffers with ONE RCCL gather over xGMI (ncclCommInitAll over the devices + grouped
+ * ncclSend / ncclRecv; librccl is loaded on first use) and the frame is assembled and tone-mapped
+ * once.  If the same device appears more than once (a one-GPU rehearsal of the partition) the
+ * shares are copied device-to-device instead: RCCL cannot put two ranks on one device.
  * The result is bit-identical to jade_render on one device.  params->tile_rank / tile_nranks /
- * device_id are ignored.  (The one-process-per-GPU form with an RCCL gather is what bench.py and
- * jaderaytracerendering_amd/distributed.py use.) */
+ * device_id are ignored.  (The one-process-per-GPU form with torch.distributed's RCCL gather is
+ * what bench.py and jaderaytracerendering_amd/distributed.py use.) */
 int jade_render_multi(jade_scene* const* scenes, int ndev, const jade_render_params* params,
                       float* out_rgb, uint8_t* out_bgr8, jade_stats* stats);
 

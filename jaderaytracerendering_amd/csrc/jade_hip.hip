@@ -22,6 +22,9 @@
 // entry points return JADE_ERR_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types only: the library is loaded on first use (jade_render_multi on distinct devices)
+
 #include <algorithm>
 #include <thread>
 #include <cstdio>
@@ -747,6 +750,77 @@ static hipError_t upload(DevBuf& b, const T* src, size_t count, hipStream_t stre
   return e;
 }
 
+// RCCL is loaded on first use (dlopen): the single-GPU product path never needs it, and a process that also hosts
+// PyTorch keeps whichever librccl it loaded first.
+namespace {
+struct Rccl {
+  void* h = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool load(std::string* why) {
+    if (h) return true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+      if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!h) { *why = std::string("cannot load librccl: ") + dlerror(); return false; }
+    auto sym = [&](const char* n) { void* p = dlsym(h, n); if (!p) *why = std::string("librccl lacks ") + n; return p; };
+    CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
+    CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+    GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
+    GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
+    Send = (decltype(Send))sym("ncclSend");
+    Recv = (decltype(Recv))sym("ncclRecv");
+    GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+    return CommInitAll && CommDestroy && GroupStart && GroupEnd && Send && Recv && GetErrorString;
+  }
+};
+Rccl g_rccl;
+}  // namespace
+
+// Gather of every share's resolved tile buffer (scenes[i]->b_out_rgb, npx * 3 floats) into `dst` on scenes[0]'s device,
+// share i at off[i]: one communicator per device from this one process, all sends and receives in one group.
+static int rccl_gather(jade_scene* const* scenes, int ndev, float* dst, const std::vector<size_t>& off) {
+  std::string why;
+  if (!g_rccl.load(&why)) return fail(JADE_ERR_DEVICE, why);
+  std::vector<int> devs(ndev);
+  for (int i = 0; i < ndev; ++i) devs[i] = scenes[i]->device;
+  std::vector<ncclComm_t> comms(ndev, nullptr);
+  ncclResult_t r = g_rccl.CommInitAll(comms.data(), ndev, devs.data());
+  if (r != ncclSuccess) return fail(JADE_ERR_DEVICE, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r));
+  auto done = [&](int rc) {
+    for (ncclComm_t c : comms)
+      if (c) (void)g_rccl.CommDestroy(c);
+    return rc;
+  };
+  r = g_rccl.GroupStart();
+  for (int i = 1; i < ndev && r == ncclSuccess; ++i) {
+    const size_t count = (size_t)scenes[i]->ps.npx * 3;
+    if (!count) continue;
+    if (hipSetDevice(scenes[i]->device) != hipSuccess) return done(fail(JADE_ERR_DEVICE, "hipSetDevice failed"));
+    r = g_rccl.Send(scenes[i]->b_out_rgb.p, count, ncclFloat, 0, comms[i], scenes[i]->stream);
+    if (r != ncclSuccess) break;
+    if (hipSetDevice(scenes[0]->device) != hipSuccess) return done(fail(JADE_ERR_DEVICE, "hipSetDevice failed"));
+    r = g_rccl.Recv(dst + off[i], count, ncclFloat, i, comms[0], scenes[0]->stream);
+  }
+  const ncclResult_t r2 = g_rccl.GroupEnd();
+  if (r == ncclSuccess) r = r2;
+  if (r != ncclSuccess) return done(fail(JADE_ERR_DEVICE, std::string("RCCL gather: ") + g_rccl.GetErrorString(r)));
+  // rank 0's own share does not travel; then every stream involved must drain before the communicators go
+  hipError_t e = hipSetDevice(scenes[0]->device);
+  const size_t own = (size_t)scenes[0]->ps.npx * 12;
+  if (e == hipSuccess && own) e = hipMemcpyAsync(dst + off[0], scenes[0]->b_out_rgb.p, own, hipMemcpyDeviceToDevice, scenes[0]->stream);
+  for (int i = ndev - 1; i >= 0 && e == hipSuccess; --i) {
+    e = hipSetDevice(scenes[i]->device);
+    if (e == hipSuccess) e = hipStreamSynchronize(scenes[i]->stream);
+  }
+  if (e != hipSuccess) return done(fail(JADE_ERR_DEVICE, std::string("RCCL gather: ") + hipGetErrorString(e)));
+  return done(JADE_OK);
+}
+
 extern "C" {
 
 int jade_abi_version(void) { return JADE_ABI_VERSION; }
@@ -1420,7 +1494,10 @@ int jade_render_multi(jade_scene* const* scenes, int ndev, const jade_render_par
   for (auto& t : th) t.join();
   for (int i = 0; i < ndev; ++i)
     if (rcs[i]) return fail(rcs[i], "device share " + std::to_string(i) + ": " + msgs[i]);
-  // 2. gather on the device of scenes[0]: peer-to-peer copies of the compact tile buffers
+  // 2. the ONE exchange step: gather the compact tile buffers on the device of scenes[0].  Distinct devices: an RCCL
+  // gather over xGMI (ncclCommInitAll + grouped send/recv, the form ncclGather itself expands to, so
+  // that ranks may contribute different tile counts).  The same device several times (a one-GPU rehearsal of the
+  // partition): RCCL cannot put two ranks on one device, the shares are copied device-to-device instead.
   jade_scene* s0 = scenes[0];
   HIP_TRY(hipSetDevice(s0->device));
   size_t total = 0;
@@ -1431,10 +1508,18 @@ int jade_render_multi(jade_scene* const* scenes, int ndev, const jade_render_par
   }
   DevBuf gather;
   HIP_TRY(gather.alloc(total * 4));
-  for (int i = 0; i < ndev; ++i) {
-    size_t bytes = (size_t)scenes[i]->ps.npx * 12;
-    if (!bytes) continue;
-    HIP_TRY(hipMemcpyPeerAsync(gather.as<float>() + off[i], s0->device, scenes[i]->b_out_rgb.p, scenes[i]->device, bytes, s0->stream));
+  bool distinct = true;
+  for (int i = 0; i < ndev; ++i)
+    for (int j = 0; j < i; ++j) distinct = distinct && scenes[i]->device != scenes[j]->device;
+  // JADE_FORCE_RCCL=1 (tests): take the RCCL path for a single share too - library load, communicator, empty group
+  if (distinct && (ndev > 1 || getenv("JADE_FORCE_RCCL"))) {
+    if (int rc = rccl_gather(scenes, ndev, gather.as<float>(), off)) return rc;
+  } else {
+    for (int i = 0; i < ndev; ++i) {
+      size_t bytes = (size_t)scenes[i]->ps.npx * 12;
+      if (!bytes) continue;
+      HIP_TRY(hipMemcpyAsync(gather.as<float>() + off[i], scenes[i]->b_out_rgb.p, bytes, hipMemcpyDeviceToDevice, s0->stream));
+    }
   }
   std::vector<float> host(total);
   HIP_TRY(hipMemcpyAsync(host.data(), gather.p, total * 4, hipMemcpyDeviceToHost, s0->stream));

@@ -115,6 +115,35 @@ def test_render_multi_equals_single_device(hip):
             assert counters(st) == counters(st_full)
 
 
+def test_render_multi_rccl_path_on_one_device(hip, monkeypatch):
+    """What of the RCCL gather can run on one GPU: librccl is found and loaded, ncclCommInitAll / group / destroy succeed
+    for a single rank, the own share is placed, the frame equals jade_render.  (Two ranks: the next test.)"""
+    monkeypatch.setenv("JADE_FORCE_RCCL", "1")
+    hs, cfg = config_scene("tinyjade")
+    p = B.params_from_config(cfg, spp=3)
+    p.width, p.height = 40, 30
+    with hip.scene(hs) as s0:
+        full, full_b, st_full = s0.render(p)
+        rgb, bgr, st = B.render_multi(hip, [s0], p)
+    assert np.array_equal(rgb.view(np.uint32), full.view(np.uint32)) and np.array_equal(bgr, full_b)
+    assert counters(st) == counters(st_full)
+
+
+def test_render_multi_over_two_devices_rccl(hip):
+    """jade_render_multi with scenes on DISTINCT devices: the shares meet through the RCCL gather (ncclCommInitAll +
+    grouped send/recv).  Needs two GPUs; the round's GPU box has one, so this runs wherever more are visible."""
+    if hip.device_count() < 2:
+        pytest.skip("one GPU visible: the RCCL gather needs two distinct devices")
+    hs, cfg = config_scene("tinyjade")
+    p = B.params_from_config(cfg, spp=6)
+    p.width, p.height = 70, 50
+    with hip.scene(hs, device_id=0) as s0, hip.scene(hs, device_id=1) as s1:
+        full, full_b, st_full = s0.render(p)
+        rgb, bgr, st = B.render_multi(hip, [s0, s1], p)
+    assert np.array_equal(rgb.view(np.uint32), full.view(np.uint32)) and np.array_equal(bgr, full_b)
+    assert counters(st) == counters(st_full)
+
+
 def test_progressive_equals_single_call(hip):
     """begin + N x step(spp) + resolve == one render of N*spp (RNG state and sums persist)."""
     hs, cfg = config_scene("tiny")
