@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the statue-filling camera variant")
     ap.add_argument("--bvh", default="sah", choices=["sah", "lbvh", "ploc"],
                     help="sah: the reference's host builder (default, what the metric is quoted on); lbvh / ploc: GPU builders")
+    ap.add_argument("--bvh-leaf", type=int, default=0, help="triangles per leaf for the GPU builders (0: 8 for lbvh as in the reference, 3 for ploc)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL) for real runs; gloo rehearses the multi-rank flow with every rank on one GPU")
     ap.add_argument("--virtual-ranks", type=int, default=0,
@@ -124,7 +125,7 @@ def main():
     if args.bvh != "sah":
         sb = J.SceneBuilder()
         cfg = sb.config(args.config)
-        hs, dev_build_ms = sb.build_device_bvh(hip, args.bvh, device_id=local_rank)
+        hs, dev_build_ms = sb.build_device_bvh(hip, args.bvh, leaf_size=args.bvh_leaf or (3 if args.bvh == "ploc" else 8), device_id=local_rank)
         sb.close()
     else:
         hs, cfg = J.build_config(args.config)

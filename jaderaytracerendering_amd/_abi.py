@@ -117,10 +117,9 @@ RT_SYMBOLS = {
 }
 
 # include/jade_bvh.h (exported by libjade_hip.so)
-BVH_SYMBOLS = {
-    "jade_bvh_build_lbvh": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int, C.c_void_p, C.c_void_p, C.c_int32,
-                                      C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
-}
+_BVH_SIG = (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32),
+                      C.POINTER(C.c_double)])
+BVH_SYMBOLS = {"jade_bvh_build_lbvh": _BVH_SIG, "jade_bvh_build_ploc": _BVH_SIG}
 
 HOST_SYMBOLS = {
     "jadeh_last_error": (C.c_char_p, []),

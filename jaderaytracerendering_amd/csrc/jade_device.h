@@ -43,7 +43,7 @@
 #define JADE_LDS_FIFO 4
 #endif
 /* leaf cursors waiting for their triangle tests, same LDS column (power of two) */
-#define JADE_LDS_STATE 8  /* ray-state words, same column (jade_trace.h): 20 words per lane */
+#define JADE_LDS_STATE 9  /* ray-state words, same column (jade_trace.h): 21 words per lane */
 // k_trace runs ONE 1024-thread workgroup per CU (4 waves/SIMD; 5 and 6 waves measured +6 % / +6 % at 256 threads, see
 // DESIGN.md): its lanes' columns take 80 KB of the CU's 160 KB of LDS and the rest holds the top of the BVH
 // (JADE_LDS_TOP_NODES node records, the ones with the largest boxes), staged once per launch.  PMC showed the kernel
@@ -52,8 +52,8 @@
 #ifndef JADE_TRACE_BLOCK
 #define JADE_TRACE_BLOCK 256
 #endif
-#ifndef JADE_LDS_TOP_NODES  /* 0 = no staging (A/B builds) */
-#define JADE_LDS_TOP_NODES 96
+#ifndef JADE_LDS_TOP_NODES  /* 0 = no staging (A/B builds); 6 blocks x (21 KB of columns + 5 KB of nodes) = 156 of the CU's 160 KB */
+#define JADE_LDS_TOP_NODES 80
 #endif
 #define JADE_RECORD_MEMORY 0.60 /* share of the free device memory that path records + partial sums may take: paths in \
                                   flight are what fills the wide passes (1080p on one GPU: 32 -> 256 records per pixel = +21 %) */

@@ -456,6 +456,9 @@ __global__ __launch_bounds__(JADE_LEAN_BLOCK) void k_shade_lean(DevScene S, Path
   shade_tail<true, JADE_LEAN_BLOCK / 64>(P, p, st, c, defer, nullptr, heavy_out, queue, qc, ctr);
 }
 
+#ifndef JADE_STRAIGHT
+#define JADE_STRAIGHT 1 /* branch-free node / triangle steps (jade_trace.h) */
+#endif
 #ifndef JADE_TRACE_NT
 #define JADE_TRACE_NT 1 /* k_trace reads and writes the ray records with non-temporal hints */
 #endif
@@ -506,6 +509,9 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
   const int npix = P.npix;
   const size_t plane = (size_t)P.nslots * npix;
   uint32_t V = 0, T = 0;  // wave totals (uniform: they live in SGPRs)
+#if JADE_STRAIGHT
+  uint32_t vcnt = 0, tcnt = 0;  // per lane, summed over the wave once at the end (a ballot + popcount per unit was 8 instructions)
+#endif
 #if JADE_TRACE_PROFILE
   uint32_t prof_units = 0, prof_lanes = 0;  // development: units run of one kind (1 node, 2 triangle, 3 any) and lanes that took part
 #endif
@@ -576,6 +582,24 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
       const bool cw = active && ray_can_walk(r), ct = active && ray_can_test(r);
       const int nw = __popcll(__ballot(cw)), nt = __popcll(__ballot(ct));
       if (JADE_COST_TRI * nw >= JADE_COST_NODE * nt) {
+#if JADE_STRAIGHT
+        // the NaN-faithful slab reduction is needed by a ray with a non-finite 1/d or origin only: decided per WAVE (a
+        // scalar branch), not per lane - such rays are rare, and the faithful form is right for every ray
+        if (__ballot(active && (int32_t)r.skipx < 0) != 0ull) {
+#pragma nounroll
+          for (int rep = 0; rep < JADE_STEPS_PER_PICK; ++rep)
+            if (active && ray_can_walk(r)) ray_step_node_s<true>(r, S, stk, vcnt);
+        } else {
+#pragma nounroll
+          for (int rep = 0; rep < JADE_STEPS_PER_PICK; ++rep) {
+#if JADE_TRACE_PROFILE == 1
+            prof_units += 1;
+            prof_lanes += (uint32_t)__popcll(__ballot(active && ray_can_walk(r)));
+#endif
+            if (active && ray_can_walk(r)) ray_step_node_s<false>(r, S, stk, vcnt);
+          }
+        }
+#else
 #pragma nounroll
         for (int rep = 0; rep < JADE_STEPS_PER_PICK; ++rep) {
           bool c1 = false, c2 = false;
@@ -587,17 +611,22 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
           if (go) ray_step_node(r, S, stk, &c1, &c2);
           V += (uint32_t)__popcll(__ballot(c1)) + (uint32_t)__popcll(__ballot(c2));
         }
+#endif
       } else {
 #pragma nounroll
         for (int rep = 0; rep < JADE_STEPS_PER_PICK; ++rep) {
-          bool tested = false;
           const bool go = active && ray_can_test(r);
 #if JADE_TRACE_PROFILE == 2
           prof_units += 1;
           prof_lanes += (uint32_t)__popcll(__ballot(go));
 #endif
+#if JADE_STRAIGHT
+          if (go) ray_step_tri_s(r, S, stk, tcnt);
+#else
+          bool tested = false;
           if (go) ray_step_tri(r, S, stk, &tested);
           T += (uint32_t)__popcll(__ballot(tested));
+#endif
         }
       }
 #if JADE_TRACE_PROFILE == 3
@@ -611,6 +640,10 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
       wb = true;
     }
   }
+#if JADE_STRAIGHT
+  V += (uint32_t)wave_sum_u32(vcnt);  // (valid in lane 0, the only lane that uses it)
+  T += (uint32_t)wave_sum_u32(tcnt);
+#endif
   if (lane == 0) {
     DevCounters* cs = ctr + (blockIdx.x % JADE_CTR_SHARDS);
 #if JADE_TRACE_PROFILE
@@ -1272,8 +1305,16 @@ static int run_passes(jade_scene* s, uint32_t target_spp, bool may_carry, double
       HIP_TRY(hipEventSynchronize(tb));
       float t = 0;
       HIP_TRY(hipEventElapsedTime(&t, ta, tb));
-      fprintf(stderr, "[jade] pass %4d active %9u rays %9u shade %7.3f ms (lean %6.3f) trace %8.3f ms (%7.1f Mray/s)\n", pass_no,
-              n_active, host_ctl[0], shade_ms, lean_ms, t, host_ctl[0] / (t * 1e3));
+      DevCounters cc{};  // development log only: node records and triangle tests of this launch (counters accumulate over the step)
+      HIP_TRY(sum_counters(s, &cc));
+      static thread_local unsigned long long v_prev = 0, t_prev = 0;
+      if (pass_no == 0 && (cc.nodes_visited < v_prev || cc.tris_tested < t_prev)) v_prev = t_prev = 0;
+      if (cc.nodes_visited < v_prev) v_prev = t_prev = 0;
+      fprintf(stderr, "[jade] pass %4d active %9u rays %9u shade %7.3f ms (lean %6.3f) trace %8.3f ms (%7.1f Mray/s) V/ray %6.1f T/ray %5.1f\n", pass_no,
+              n_active, host_ctl[0], shade_ms, lean_ms, t, host_ctl[0] / (t * 1e3), (double)(cc.nodes_visited - v_prev) / host_ctl[0],
+              (double)(cc.tris_tested - t_prev) / host_ctl[0]);
+      v_prev = cc.nodes_visited;
+      t_prev = cc.tris_tested;
     }
     ++pass_no;
     if (carried) break;

@@ -48,6 +48,9 @@ struct TraceHit {
 #ifndef JADE_ABLATE_SLAB
 #define JADE_ABLATE_SLAB 0
 #endif
+#ifndef JADE_ABLATE_LOAD
+#define JADE_ABLATE_LOAD 0
+#endif
 
 // A lane's column of LDS words, lds[word * JADE_TRACE_BLOCK + tid] (bank-conflict free):
 // words [0, JADE_LDS_STACK) are the traversal stack, the JADE_LDS_STATE words after it hold
@@ -61,7 +64,9 @@ struct LdsStack {
 };
 enum {
   LW_FIFO = JADE_LDS_STACK,  // JADE_LDS_FIFO leaf cursors waiting for their triangle tests (ring)
-  LW_INVX = JADE_LDS_STACK + JADE_LDS_FIFO, LW_INVY, LW_INVZ, LW_BEST_DIST, LW_BEST_INDEX, LW_PX, LW_PY, LW_PZ, LW_END
+  LW_INVX = JADE_LDS_STACK + JADE_LDS_FIFO, LW_INVY, LW_INVZ, LW_BEST_DIST, LW_BEST_INDEX, LW_PX, LW_PY, LW_PZ,
+  LW_DUMMY,  // where a lane's store goes when the statement it belongs to does not apply to that lane (straight-line steps below)
+  LW_END
 };
 static_assert(LW_END - LW_INVX == JADE_LDS_STATE, "JADE_LDS_STATE must count the LW_* state words");
 static_assert((JADE_LDS_FIFO & (JADE_LDS_FIFO - 1)) == 0, "JADE_LDS_FIFO must be a power of two");
@@ -360,6 +365,12 @@ static __device__ __forceinline__ void ray_step_node(RayState& r, const DevScene
       gb = nd[1];
       gc = nd[2];
       grf = *reinterpret_cast<const uint2*>(nd + 3);
+#if JADE_ABLATE_LOAD
+      {  // prices the vector-memory path: one more 16-B gather per lane from the line just fetched (+25 % look-ups, same bytes from L2)
+        const float4 x = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(nd) + 40);
+        asm volatile("" ::"v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w));
+      }
+#endif
     }
     a = ga;
     b = gb;
@@ -417,4 +428,129 @@ static __device__ __forceinline__ void ray_step_node(RayState& r, const DevScene
   if (leafv) leaf_queue(r, stk, leafv);
   if (need_pop) cur = walk_pop(r, stk);
   r.cur = cur;  // may be a leaf (the far child, a popped one, or one that found no room): the next step queues it
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Straight-line forms of the two steps (JADE_STRAIGHT, the default).  Same statements, same results; what changes
+// is that no decision is a branch.  k_trace is bound by instruction issue, and the nested ifs above cost it twice:
+// every `if` is 3-4 scalar instructions of EXEC bookkeeping in the wave's (serial) instruction stream - scalar and
+// branch instructions were 40 % of all instructions issued - and each side of it runs for a part of the lanes only
+// (31.7 of 64 lanes per VALU instruction although 39 had work of the picked kind).  Here a decision selects values
+// (v_cndmask) and, where it guards a store, the store's ADDRESS: a lane the statement does not apply to writes its
+// column's LW_DUMMY word (LDS is 7 % busy).  Only the rare cases stay branches: a stack deeper than its LDS levels
+// (0.4 % of the rays) and a triangle that is actually hit.
+// ---------------------------------------------------------------------------------------------------------------
+static __device__ __forceinline__ void lds_put_w(const LdsStack& s, uint32_t word, uint32_t v) { s.lds[word * JADE_TRACE_BLOCK] = v; }
+static __device__ __forceinline__ uint32_t lds_get_w(const LdsStack& s, uint32_t word) { return s.lds[word * JADE_TRACE_BLOCK]; }
+
+// One unit of the node walk for a lane with ray_can_walk.  vcnt: this lane's count of child records visited.
+template <bool EXACT>
+static __device__ __forceinline__ void ray_step_node_s(RayState& r, const DevScene& S, const LdsStack& stk, uint32_t& vcnt) {
+  const uint32_t cur = r.cur;
+  const bool is_leaf = (cur & JADE_REF_LEAF) != 0;  // left over from a step that could not queue it (room was checked by ray_can_walk)
+  const uint32_t node = is_leaf ? 0u : cur;         // such a lane reads record 0 and ignores it
+  float4 a, b, c;
+  uint2 rf;
+#if JADE_LDS_TOP_NODES > 0
+  {
+    const bool in_top = node < stk.top_k;
+    const float4* t = stk.top + (in_top ? node : 0u);
+    const float4 la = t[0], lb = t[stk.top_k], lc = t[2 * stk.top_k], lr = t[3 * stk.top_k];
+    a = la;
+    b = lb;
+    c = lc;
+    rf = make_uint2(jade_f2u(lr.x), jade_f2u(lr.y));
+    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w));  // see ray_step_node
+    asm volatile("" : "+v"(c.x), "+v"(c.y), "+v"(c.z), "+v"(c.w), "+v"(rf.x), "+v"(rf.y));
+    if (!in_top) {
+      const float4* nd = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.nodes) + node * 64u);
+      a = nd[0];
+      b = nd[1];
+      c = nd[2];
+      rf = *reinterpret_cast<const uint2*>(nd + 3);
+    }
+  }
+#else
+  {
+    const float4* nd = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.nodes) + node * 64u);
+    a = nd[0];
+    b = nd[1];
+    c = nd[2];
+    rf = *reinterpret_cast<const uint2*>(nd + 3);
+  }
+#endif
+  const jvec3 inv = jv(lds_getf(stk, LW_INVX), lds_getf(stk, LW_INVY), lds_getf(stk, LW_INVZ));
+  float d1, d2;
+  slab2(r.od, inv, a, b, c, EXACT, &d1, &d2);
+  const bool c1 = !is_leaf && rf.x != JADE_REF_NONE, c2 = !is_leaf && rf.y != JADE_REF_NONE;  // a missing child is neither counted nor entered
+  vcnt += (c1 ? 1u : 0u) + (c2 ? 1u : 0u);
+  const bool in1 = c1 && d1 > 0, in2 = c2 && d2 > 0;
+  const bool both = in1 && in2, any = in1 || in2;
+  const bool first = d1 < d2;  // near child first, PathTrace.cu:835-848
+  const uint32_t near = both ? (first ? rf.x : rf.y) : (in1 ? rf.x : rf.y);
+  const uint32_t far = first ? rf.y : rf.x;
+  const bool room = leaf_room(r);
+  const bool near_leaf_ok = any && (near & JADE_REF_LEAF) != 0 && room;  // the near leaf is met now
+  // both, near leaf met: the far child is next, nothing to push.  both otherwise: push far, go near.  one: go there (a
+  // leaf that is met ends the branch: pop).  none: pop.
+  const uint32_t leafv = is_leaf ? cur : (near_leaf_ok ? near : 0u);
+  const bool push = both && !near_leaf_ok;
+  const uint32_t next = both ? (near_leaf_ok ? far : near) : near;
+  const bool need_pop = is_leaf || !any || (!both && near_leaf_ok);
+  uint32_t ctl = r.ctl;
+  // ---- leaf_queue
+  {
+    const bool lq = (leafv & 15u) != 0;  // (an empty leaf cannot happen for a valid BVH)
+    const bool to_fifo = lq && r.leaf != 0;
+    const uint32_t slot = ((ctl >> 8) + (ctl >> 16)) & (JADE_LDS_FIFO - 1);
+    lds_put_w(stk, to_fifo ? (uint32_t)LW_FIFO + slot : (uint32_t)LW_DUMMY, leafv);
+    r.leaf = (lq && r.leaf == 0) ? leafv : r.leaf;
+    ctl += to_fifo ? (1u << 16) : 0u;
+  }
+  // ---- push the far child
+  uint32_t sp = ctl & 0xffu;
+  lds_put_w(stk, (push && sp < JADE_LDS_STACK) ? sp : (uint32_t)LW_DUMMY, far);
+  if (push && sp >= JADE_LDS_STACK) stk.spill[(size_t)(sp - JADE_LDS_STACK) * stk.stride_spill] = far;  // rare
+  sp += push ? 1u : 0u;
+  // ---- pop (a lane pushes or pops, never both)
+  const bool do_pop = need_pop && sp > 0;
+  const uint32_t sp1 = sp - 1u;
+  uint32_t top = lds_get_w(stk, (do_pop && sp1 < JADE_LDS_STACK) ? sp1 : (uint32_t)LW_DUMMY);
+  asm volatile("" : "+v"(top));  // keeps the LDS read a ds_read (see stack_pop)
+  if (do_pop && sp1 >= JADE_LDS_STACK) top = stk.spill[(size_t)(sp1 - JADE_LDS_STACK) * stk.stride_spill];  // rare
+  sp -= do_pop ? 1u : 0u;
+  r.cur = need_pop ? (do_pop ? top : JADE_REF_NONE) : next;
+  r.ctl = (ctl & ~0xffu) | sp;
+}
+
+// One triangle of the leaf at the head of the FIFO for a lane with ray_can_test.  tcnt: this lane's count of tests.
+static __device__ __forceinline__ void ray_step_tri_s(RayState& r, const DevScene& S, const LdsStack& stk, uint32_t& tcnt) {
+  const uint32_t off = r.leaf & 0x7ffffff0u;
+  const char* t0 = reinterpret_cast<const char*>(S.tverts) + off;
+  const float4 q0 = *reinterpret_cast<const float4*>(t0);
+  const float2 q1 = *reinterpret_cast<const float2*>(t0 + 16);
+  const V3ld q3 = *reinterpret_cast<const V3ld*>(t0 + 24);
+  const jvec3 p3 = jv(q3.x, q3.y, q3.z);
+  uint32_t leaf = r.leaf + 47u;  // next record, count - 1
+  const bool tested = off != (r.skipx & 0x7fffffffu);  // the source triangle is skipped by index, PathTrace.cu:782
+  tcnt += tested ? 1u : 0u;
+  float dist;
+  jvec3 P;
+  if (tested && tri_test(q0, q1, p3, r.od, &dist, &P) && dist < lds_getf(stk, LW_BEST_DIST)) {  // a hit: rare
+    lds_putf(stk, LW_BEST_DIST, dist);
+    lds_put(stk, LW_BEST_INDEX, off);
+    lds_putf(stk, LW_PX, P.x);
+    lds_putf(stk, LW_PY, P.y);
+    lds_putf(stk, LW_PZ, P.z);
+  }
+  // leaf finished: the next one from the FIFO, if any
+  const bool fin = (leaf & 15u) == 0;
+  const uint32_t ctl = r.ctl;
+  const bool has = ((ctl >> 16) & 0xffu) != 0;
+  const uint32_t head = (ctl >> 8) & 0xffu;
+  const uint32_t nxt = lds_get_w(stk, (uint32_t)LW_FIFO + (head & (JADE_LDS_FIFO - 1)));
+  const uint32_t ctl2 = (ctl & 0xffff00ffu) - (1u << 16) + (((head + 1u) & (JADE_LDS_FIFO - 1)) << 8);
+  r.leaf = fin ? (has ? nxt : 0u) : leaf;
+  r.ctl = (fin && has) ? ctl2 : ctl;
 }
