@@ -21,8 +21,9 @@ value = (primary + secondary rays traced by all ranks in the K timed steps) / ma
 roofline: the dominant kernel, k_trace (BVH traversal + triangle tests), against the roof that BINDS it: VALU
         issue.  achieved = VALU lane-operations per second = (lane-ops per ray, SQ_THREAD_CYCLES_VALU from the
         rocprofv3 --pmc pass of this same command, profiles/valu_issue.json) x (rays this run traced) / (k_trace
-        time of this run, HIP events on the kernel's own stream); peak = 1024 SIMDs x 32 lanes x 2.4 GHz.  frac is
-        therefore (lanes active per VALU instruction / 64) x (share of cycles the VALU pipes issue), <= 1.
+        time of this run, HIP events on the kernel's own stream); peak = 1024 SIMDs x 16 lane-ops per clock x 2.4 GHz
+        (one wave64 VALU instruction per SIMD per 4 clocks, see VALU_PEAK_TLANEOPS).  frac is therefore (lanes active
+        per VALU instruction / 64) x (share of quad-cycles in which the SIMD's VALU issues) x (clock held / 2.4 GHz), <= 1.
 roofline_hbm: the HBM view SURVEY.md 8d prices the path with.  achieved = MEASURED HBM bytes (PMC FETCH_SIZE x 2 +
         WRITE_SIZE per ray, profiles/hbm_traffic.json) x rays / k_trace time, against 8 TB/s; `algorithmic_GBps` is
         the reference traversal's 40 B per node record + 36 B per triangle test delivered per second — it exceeds
@@ -44,7 +45,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s
-VALU_PEAK_TLANEOPS = 1024 * 32 * 2.4e9 / 1e12  # 256 CUs x 4 SIMD-32, one lane-op per lane per clock, 2.4 GHz = 78.6
+# VALU issue roof: one wave64 VALU instruction per SIMD per 4 clocks = 16 lane-ops per clock per SIMD.  That is the unit the SQ
+# itself counts in (SQ_ACTIVE_INST_VALU = 1.007 quad-cycles per VALU instruction in every kernel here) and the rate at which
+# k_trace saturates: its time follows its VALU instruction count (ablations) with 4 x ACTIVE_INST_VALU / SIMD-cycles
+# at 0.99.  MI355X_MICROARCH.md's 2-clock figure holds for independent back-to-back v_fma pairs (SQ_ACTIVE_INST_VALU2: 14 % of
+# this kernel's quad-cycles); against that ideal every fraction below is halved (frac_if_dual_issue).
+VALU_PEAK_TLANEOPS = 1024 * 16 * 2.4e9 / 1e12  # 256 CUs x 4 SIMDs, 2.4 GHz = 39.3 T lane-ops/s
 
 
 def parse():
@@ -207,12 +213,13 @@ def main():
                 "rays_per_launch": rays_rank / launches}
         if valu and valu.get("valu_lane_ops_per_ray") and trace_s > 0:
             ach = valu["valu_lane_ops_per_ray"] * rays_rank / trace_s / 1e12
-            roof.update({"achieved": ach, "frac": ach / VALU_PEAK_TLANEOPS, "valu_lane_ops_per_ray": valu["valu_lane_ops_per_ray"],
+            roof.update({"achieved": ach, "frac": ach / VALU_PEAK_TLANEOPS, "frac_if_dual_issue": ach / (2 * VALU_PEAK_TLANEOPS),
+                         "valu_lane_ops_per_ray": valu["valu_lane_ops_per_ray"], "valu_wave_insts_per_ray": valu.get("valu_wave_insts_per_ray"),
                          "lanes_per_valu_inst_of_64": valu.get("lanes_per_valu_inst"), "valu_busy_profiled": valu.get("valu_busy"),
                          "counters_from": valu.get("source"),
                          "note": "lane-ops per ray from the rocprofv3 --pmc SQ pass of this command (tracked summary named in "
-                                 "counters_from); rays and k_trace time are this run's.  frac = share of the chip's VALU lane-cycles "
-                                 "that carry a lane of this kernel's work"})
+                                 "counters_from); rays and k_trace time are this run's.  frac = (lanes of 64 per VALU instruction) x (share of "
+                                 "quad-cycles the VALU issues) x (clock / 2.4 GHz): the share of the chip's VALU lane-slots doing this kernel's work"})
         roof_hbm = {"bound": "hbm", "kernel": "k_trace", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                     "algorithmic_GBps": alg_bytes / trace_s / 1e9 if trace_s > 0 else None,
                     "algorithmic_bytes_per_launch": alg_bytes / launches,

@@ -149,8 +149,17 @@ __global__ __launch_bounds__(JADE_ARM_BLOCK) void k_arm(PathState P, uint32_t ta
     if (wantm & (1u << j)) active_out[blk + sh_cnt[j * NW + w] + off[j]] = (uint32_t)(base + (size_t)j * JADE_ARM_BLOCK + threadIdx.x);
 }
 
+// A step hands its unfinished paths to the next step (or to flush) once fewer than JADE_CARRY_FRACTION of the records it
+// started with are still active.  The paths left are the long ones (jade: ~10 bounces against 1-2 for the sky and the
+// mirror floor): finishing them inside every step means dozens of thin passes per step, whose sparse record accesses
+// waste most of every cache line; carried over, they ride along with the next step's full passes and the thin tail
+// is paid once per render (C3: 364 -> 286 k_trace launches per 4096 spp, +3 % Mray/s at 0.02; 0.07 and 0.2 measure the
+// same).  JADE_CARRY_FRACTION in the environment overrides it (0 = only the absolute floor below).
+#ifndef JADE_CARRY_FRACTION
+#define JADE_CARRY_FRACTION 0.02
+#endif
 #ifndef JADE_CARRY_RECORDS
-#define JADE_CARRY_RECORDS 32768u /* a step hands its last paths to the next one once fewer than this (and < 0.1 % of its records) are active */
+#define JADE_CARRY_RECORDS 32768u /* ... and in any case once fewer than this (and < 0.1 % of its records) are active */
 #endif
 #ifndef JADE_SHADE_BLOCK
 #define JADE_SHADE_BLOCK 512 /* threads per k_shade block: one queue + one list atomic per block (512: +1.8 % over 256; 1024: none) */
@@ -422,7 +431,7 @@ static __device__ __forceinline__ void shade_tail(const PathState& P, int p, uin
 }
 
 // The full shade kernel: one thread per entry of `list` (the active list, or — after k_shade_lean —
-// the records that kernel handed over, whose count lives on the device: n_dev).  128 VGPRs, 4 waves/SIMD.
+// the records that kernel handed over, whose count lives on the device: n_dev).  75 VGPRs, 6 waves/SIMD (JADE_SHADE_WAVES).
 __global__ __launch_bounds__(JADE_SHADE_BLOCK, JADE_SHADE_WAVES) void k_shade(DevScene S, PathState P, RenderConst R, const int32_t* tile_ids,
                                                uint32_t target_spp, const uint32_t* list, uint32_t n_host, const uint32_t* n_dev,
                                                uint32_t* active_out, uint32_t* queue, QueueCtl* qc, DevCounters* ctr) {
@@ -456,6 +465,11 @@ __global__ __launch_bounds__(JADE_LEAN_BLOCK) void k_shade_lean(DevScene S, Path
   shade_tail<true, JADE_LEAN_BLOCK / 64>(P, p, st, c, defer, nullptr, heavy_out, queue, qc, ctr);
 }
 
+#ifndef JADE_DUAL
+#define JADE_DUAL 0 /* two rays per lane: a lane whose ray has no work of the picked kind works on its other ray */
+#endif
+#define JADE_CTX_WORDS (JADE_LDS_STACK + JADE_LDS_FIFO + JADE_LDS_STATE) /* LDS words per lane and ray context */
+#define JADE_TRACE_CTXS (JADE_DUAL ? 2 : 1)
 #ifndef JADE_STRAIGHT
 #define JADE_STRAIGHT 1 /* branch-free node / triangle steps (jade_trace.h) */
 #endif
@@ -486,7 +500,7 @@ __global__ __launch_bounds__(JADE_LEAN_BLOCK) void k_shade_lean(DevScene S, Path
 #endif
 __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(DevScene S, PathState P, const uint32_t* queue, QueueCtl* qc,
                                                            uint32_t* spill, DevCounters* ctr, uint32_t chunk) {
-  __shared__ uint32_t lds_cols[(JADE_LDS_STACK + JADE_LDS_FIFO + JADE_LDS_STATE) * JADE_TRACE_BLOCK];
+  __shared__ uint32_t lds_cols[JADE_TRACE_CTXS * JADE_CTX_WORDS * JADE_TRACE_BLOCK];
   const int lane = threadIdx.x & 63;
   const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
   LdsStack stk;
@@ -515,6 +529,157 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
 #if JADE_TRACE_PROFILE
   uint32_t prof_units = 0, prof_lanes = 0;  // development: units run of one kind (1 node, 2 triangle, 3 any) and lanes that took part
 #endif
+#if JADE_DUAL
+  {
+    // ---- two ray contexts per lane.  The walk and the tests of ONE ray take turns (a wave iteration runs one kind of work),
+    // so in any iteration a third of the lanes that hold a ray have nothing of the picked kind (39 of 64 lanes worked per
+    // unit, PMC).  With two rays per lane, a lane takes part whenever EITHER ray has work of that kind: the working copy
+    // (registers) is filled from the chosen context before the units of a pick and written back after them.
+    static_assert(JADE_STRAIGHT, "the dual-context loop uses the straight-line steps");
+    struct Ctx {
+      RayState r;
+      uint32_t e;   // queue entry: slot * npix + record
+      bool active;  // holds a ray in flight
+      bool wb;      // its ray has finished and the result is still in the LDS column
+    };
+    Ctx A, B;
+    A.active = B.active = A.wb = B.wb = false;
+    A.e = B.e = 0;
+    A.r = RayState{};
+    B.r = RayState{};
+    LdsStack stkA = stk, stkB = stk;
+    stkB.lds = stk.lds + JADE_CTX_WORDS * JADE_TRACE_BLOCK;
+    stkB.spill = stk.spill + (size_t)(JADE_BVH_STACK_CAPACITY - JADE_LDS_STACK) * stk.stride_spill;
+    uint32_t lbase = 0, lend = 0;
+    bool queue_empty = false;
+    // write back the finished rays of one context and refill its idle lanes, once >= JADE_REFILL_MIN of them are idle
+    auto refill = [&](Ctx& c, const LdsStack& ck) {
+      const unsigned long long idle = __ballot(!c.active);
+      const int n_idle = __popcll(idle);
+      if (n_idle < JADE_REFILL_MIN) return;
+      if (c.wb) {
+        const int32_t best = ray_best_index(ck);
+        NT_ST(&P.hit[c.e], best);
+        if (P.hdist) P.hdist[c.e] = lds_getf(ck, LW_BEST_DIST);
+        if (best >= 0) {
+          const jvec3 hp = ray_hit_point(ck);
+          float* hb = P.hpt + c.e;
+          NT_ST(&hb[0], hp.x);
+          NT_ST(&hb[plane], hp.y);
+          NT_ST(&hb[2 * plane], hp.z);
+        }
+        c.wb = false;
+      }
+      if (queue_empty) return;
+      if (lbase >= lend) {
+        uint32_t nb = 0;
+        if (lane == 0) nb = atomicAdd(&qc->next, chunk);
+        nb = __shfl(nb, 0, 64);
+        if (nb >= n) {
+          queue_empty = true;
+          lbase = lend = n;
+        } else {
+          lbase = nb;
+          lend = nb + chunk < n ? nb + chunk : n;
+        }
+      }
+      const uint32_t avail = lend - lbase;
+      const uint32_t take = (uint32_t)n_idle < avail ? (uint32_t)n_idle : avail;
+      const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+      if (!c.active && rank < take) {
+        c.e = NT_LD(&queue[lbase + rank]);
+        const uint32_t k = c.e / (uint32_t)npix, p = c.e - k * (uint32_t)npix;
+        const int32_t skip = NT_LD(&P.skip[p]);
+        const jvec3 o = skip == JADE_SKIP_CAMERA ? jv(P.eye[0], P.eye[1], P.eye[2])
+                                                 : jv(NT_LD(&P.org[p]), NT_LD(&P.org[npix + p]), NT_LD(&P.org[2 * npix + p]));
+        const float* db = P.dir + c.e;
+        const jvec3 d = jv(NT_LD(&db[0]), NT_LD(&db[plane]), NT_LD(&db[2 * plane]));
+        ray_begin(c.r, ck, S, o, d, skip);
+        c.active = true;
+      }
+      V += take;  // the root record of every ray started
+      lbase += take;
+    };
+    for (;;) {
+      refill(A, stkA);
+      refill(B, stkB);
+      if (queue_empty && __ballot(A.active || B.active) == 0ull) {
+        // results still parked in a column (fewer than JADE_REFILL_MIN lanes were idle when the ray ended) are written now
+        if (__ballot(A.wb || B.wb) == 0ull) break;
+        const bool sa = A.active, sb = B.active;  // (both false here)
+        (void)sa; (void)sb;
+        // force the write-back: every lane is idle, so n_idle = 64 >= JADE_REFILL_MIN
+        refill(A, stkA);
+        refill(B, stkB);
+        break;
+      }
+      const bool cwA = A.active && ray_can_walk(A.r), cwB = B.active && ray_can_walk(B.r);
+      const bool ctA = A.active && ray_can_test(A.r), ctB = B.active && ray_can_test(B.r);
+      const int nw = __popcll(__ballot(cwA || cwB)), nt = __popcll(__ballot(ctA || ctB));
+      const bool node_kind = JADE_COST_TRI * nw >= JADE_COST_NODE * nt;
+      // which context works: the one that has this kind of work; if both do, the one with nothing of the OTHER kind
+      // (it would sit out the other kind's picks anyway), else A
+      const bool selB = node_kind ? (cwB && (!cwA || (ctA && !ctB))) : (ctB && (!ctA || (cwA && !cwB)));
+      const bool go0 = node_kind ? (cwA || cwB) : (ctA || ctB);
+      RayState w;
+      w.od.a = selB ? B.r.od.a : A.r.od.a;
+      w.od.b = selB ? B.r.od.b : A.r.od.b;
+      w.od.c = selB ? B.r.od.c : A.r.od.c;
+      w.skipx = selB ? B.r.skipx : A.r.skipx;
+      w.cur = selB ? B.r.cur : A.r.cur;
+      w.leaf = selB ? B.r.leaf : A.r.leaf;
+      w.ctl = selB ? B.r.ctl : A.r.ctl;
+      LdsStack wk = stkA;
+      wk.lds = selB ? stkB.lds : stkA.lds;
+      wk.spill = selB ? stkB.spill : stkA.spill;
+      if (node_kind) {
+        if (__ballot(go0 && (int32_t)w.skipx < 0) != 0ull) {
+#pragma nounroll
+          for (int rep = 0; rep < JADE_STEPS_PER_PICK; ++rep)
+            if (go0 && ray_can_walk(w)) ray_step_node_s<true>(w, S, wk, vcnt);
+        } else {
+#pragma nounroll
+          for (int rep = 0; rep < JADE_STEPS_PER_PICK; ++rep) {
+#if JADE_TRACE_PROFILE == 1
+            prof_units += 1;
+            prof_lanes += (uint32_t)__popcll(__ballot(go0 && ray_can_walk(w)));
+#endif
+            if (go0 && ray_can_walk(w)) ray_step_node_s<false>(w, S, wk, vcnt);
+          }
+        }
+      } else {
+#pragma nounroll
+        for (int rep = 0; rep < JADE_STEPS_PER_PICK; ++rep) {
+#if JADE_TRACE_PROFILE == 2
+          prof_units += 1;
+          prof_lanes += (uint32_t)__popcll(__ballot(go0 && ray_can_test(w)));
+#endif
+          if (go0 && ray_can_test(w)) ray_step_tri_s(w, S, wk, tcnt);
+        }
+      }
+      // write the working copy back (the origin / direction / skip of a ray never change)
+      if (go0) {
+        if (selB) {
+          B.r.cur = w.cur;
+          B.r.leaf = w.leaf;
+          B.r.ctl = w.ctl;
+        } else {
+          A.r.cur = w.cur;
+          A.r.leaf = w.leaf;
+          A.r.ctl = w.ctl;
+        }
+      }
+      if (A.active && ray_done(A.r)) {
+        A.active = false;
+        A.wb = true;
+      }
+      if (B.active && ray_done(B.r)) {
+        B.active = false;
+        B.wb = true;
+      }
+    }
+  }
+#else
   // wave-local chunk of the queue: [lbase, lend) (wave-uniform)
   uint32_t lbase = 0, lend = 0;
   bool queue_empty = false;
@@ -525,7 +690,8 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
   for (;;) {
     // ---- once enough lanes are idle (or all are): write their results back and refill them.
     // Both are done for >= JADE_REFILL_MIN lanes at a time, not whenever a single ray ends:
-    // the kernel is VALU-bound and a block that runs for one lane costs as much as for 64.
+    // the kernel is bound by VALU issue (PMC: the VALU of every SIMD busy 92-94 % of the time) and a
+    // block that runs for one lane costs as much as for 64.
     const unsigned long long idle = __ballot(!active);
     const int n_idle = __popcll(idle);
     if (n_idle >= JADE_REFILL_MIN) {
@@ -640,6 +806,7 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
       wb = true;
     }
   }
+#endif  // JADE_DUAL
 #if JADE_STRAIGHT
   V += (uint32_t)wave_sum_u32(vcnt);  // (valid in lane 0, the only lane that uses it)
   T += (uint32_t)wave_sum_u32(tcnt);
@@ -1104,7 +1271,7 @@ static int setup_state(jade_scene* s, int npx, int rpp, int nslots) {
   HIP_TRY(s->b_active[0].alloc(N * 4));
   HIP_TRY(s->b_active[1].alloc(N * 4));
   if (!s->b_spill.p)
-    HIP_TRY(s->b_spill.alloc((size_t)(JADE_BVH_STACK_CAPACITY - JADE_LDS_STACK) * s->trace_blocks * JADE_TRACE_BLOCK * 4));
+    HIP_TRY(s->b_spill.alloc((size_t)JADE_TRACE_CTXS * (JADE_BVH_STACK_CAPACITY - JADE_LDS_STACK) * s->trace_blocks * JADE_TRACE_BLOCK * 4));
   return JADE_OK;
 }
 
@@ -1295,7 +1462,9 @@ static int run_passes(jade_scene* s, uint32_t target_spp, bool may_carry, double
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(tb, s->stream));
     trace_pending = true;
-    if (may_carry && n_active < JADE_CARRY_RECORDS && (uint64_t)n_active * 1024 < (uint64_t)n_armed) {
+    static const double carry_frac = getenv("JADE_CARRY_FRACTION") ? atof(getenv("JADE_CARRY_FRACTION")) : JADE_CARRY_FRACTION;
+    if (may_carry && ((n_active < JADE_CARRY_RECORDS && (uint64_t)n_active * 1024 < (uint64_t)n_armed) ||
+                      (carry_frac > 0 && (double)n_active < carry_frac * (double)n_armed))) {
       // The few long paths left would take dozens of nearly empty passes: leave them suspended (their
       // rays are traced, their hits wait to be folded in) for the next step's first pass, or for flush.
       s->tail_pending = true;
@@ -1624,7 +1793,7 @@ int jade_trace_rays(jade_scene* s, int32_t n, const float* origins, const float*
   HIP_TRY(b_hdist.alloc(N * 4));
   HIP_TRY(hipMemsetAsync(b_hpt.p, 0, 3 * N * 4, s->stream));  // the hit point of a miss is never written: report zeros
   HIP_TRY(upload(b_q, q.data(), N, s->stream));
-  HIP_TRY(b_spill.alloc((size_t)(JADE_BVH_STACK_CAPACITY - JADE_LDS_STACK) * s->trace_blocks * JADE_TRACE_BLOCK * 4));
+  HIP_TRY(b_spill.alloc((size_t)JADE_TRACE_CTXS * (JADE_BVH_STACK_CAPACITY - JADE_LDS_STACK) * s->trace_blocks * JADE_TRACE_BLOCK * 4));
   PathState P{};
   P.npix = n;
   P.nslots = 1;

@@ -2,7 +2,7 @@
 # GPU box: the round-2 measurement set behind profiles/<tag>_*.
 #   1. the default bench run                               -> bench.json
 #   2. the same command under rocprofv3 --kernel-trace --stats
-#   3. one rocprofv3 --pmc pass per counter group over the SAME default command (no CPU baseline):
+#   3. one rocprofv3 --pmc pass per counter group over the SAME default command (without the CPU baseline and the close-up extra):
 #      SQ issue counters (the VALU roofline), FETCH_SIZE, WRITE_SIZE, L2 hits
 #   4. (with C5 as 2nd argument) kernel stats + the same counter groups for --config C5, where the
 #      geometry leaves the per-XCD L2
@@ -17,12 +17,12 @@ cd /tmp && export TMPDIR=/tmp
 SQ="SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU"
 timeout -k 10 600 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 tail -c 400 $O/bench.json; echo
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --no-cpu-baseline > $O/bench_profiled.json 2> $O/stats.log
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --no-cpu-baseline --no-extras > $O/bench_profiled.json 2> $O/stats.log
 echo "stats done"
 i=0
 for grp in "$SQ" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  timeout -k 10 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/pmc_g$i -- python3 $R/bench.py --no-cpu-baseline > $O/pmc_g$i.log 2>&1 || echo "pmc group $i failed"
+  timeout -k 10 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/pmc_g$i -- python3 $R/bench.py --no-cpu-baseline --no-extras > $O/pmc_g$i.log 2>&1 || echo "pmc group $i failed"
   echo "pmc group $i done"
 done
 if [ "$2" = "C5" ]; then

@@ -24,7 +24,7 @@ tag = sys.argv[1]
 O = os.path.join(ROOT, "gpurun_out", tag)
 KERNELS = ("k_trace", "k_shade", "k_shade_lean", "k_arm", "k_resolve", "k_init")
 N_CU, N_SIMD = 256, 1024
-VALU_PEAK_LANE_OPS = N_SIMD * 32 * 2.4e9  # 4 SIMD-32 per CU, one lane-op per lane per clock, 2.4 GHz (MI355X_MICROARCH.md)
+VALU_PEAK_LANE_OPS = N_SIMD * 16 * 2.4e9  # one wave64 VALU instruction per SIMD per 4 clocks (bench.py, VALU_PEAK_TLANEOPS)
 
 
 def reduce_dir(d):
@@ -101,7 +101,7 @@ def cut(pre, red, label, command):
                          "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU --kernel-trace --output-format csv -- python3 bench.py " + command,
               "derived": "lanes_per_valu_inst = SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU (of 64); valu_busy = 4 * SQ_ACTIVE_INST_VALU / 1024 SIMDs "
                          "/ (SQ_BUSY_CU_CYCLES / 256 CUs); lane_ops = SQ_THREAD_CYCLES_VALU (one per active lane per VALU instruction); "
-                         "VALU peak = 1024 SIMDs x 32 lanes x 2.4 GHz = 78.6 T lane-ops/s",
+                         "VALU peak = 1024 SIMDs x 16 lane-ops/clock x 2.4 GHz = 39.3 T lane-ops/s (one wave64 instruction per SIMD per 4 clocks)",
               "rays_of_profiled_run": b.get("rays"), "kernels": {}}
         for k, v in g1["kernels"].items():
             blk = sq_block(v)
@@ -140,8 +140,6 @@ def cut(pre, red, label, command):
             summ["k_trace_hbm_GBps_profiled"] = hbm / secs / 1e9
             summ["k_trace_l2_hit_rate"] = t["TCC_HIT_sum"]["sum"] / (t["TCC_HIT_sum"]["sum"] + t["TCC_MISS_sum"]["sum"])
             if b.get("roofline"):
-                rl = b["roofline"]
-                alg = rl["algorithmic_bytes_per_launch"] * rl["launches"] / rl.get("timed_launch_share_of_rays", 1.0)
                 rays_all = b.get("rays_incl_warmup_this_rank") or b["rays"] / b["steps"] * (b["steps"] + b["warmup"])
                 summ["k_trace_hbm_bytes_per_ray"] = hbm / rays_all
                 summ["rays_of_profiled_process"] = rays_all
@@ -164,7 +162,7 @@ def main():
         reduce_all()
         return
     red = json.load(open(os.path.join(O, "reduced.json")))
-    c3 = cut("", red, "C3", "--no-cpu-baseline")
+    c3 = cut("", red, "C3", "--no-cpu-baseline --no-extras")
     c5 = cut("c5_", red, "C5", "--config C5 --steps 2 --warmup 1 --spp-per-step 64 --no-cpu-baseline")
     P = os.path.join(ROOT, "profiles")
 
