@@ -196,8 +196,9 @@ def main():
 
     if rank == 0:
         # rooflines of the dominant kernel (k_trace) on THIS rank
-        rays_rank = float(st.rays_primary + st.rays_secondary)
-        alg_bytes = 40.0 * st.nodes_visited + 36.0 * st.tris_tested
+        # k_trace traces what the fused first-pass kernel (k_light: camera rays, floor mirrors) did not trace itself
+        rays_rank = float(st.rays_primary + st.rays_secondary - st.rays_inline)
+        alg_bytes = 40.0 * st.nodes_visited + 36.0 * st.tris_tested  # (whole step: V and T are not split by kernel)
         launches = max(int(st.trace_launches), 1)
         trace_s = st.trace_ms * 1e-3
         # per-ray counter figures exist for the configurations that were profiled (same scene, frame and BVH)
@@ -210,7 +211,8 @@ def main():
                 # what a profiler sees for the same command: every k_trace launch of the process, warm-up included
                 "launches_incl_warmup": launches + int(st_w.trace_launches),
                 "avg_launch_ms_incl_warmup": (st.trace_ms + st_w.trace_ms) / max(launches + int(st_w.trace_launches), 1),
-                "rays_per_launch": rays_rank / launches}
+                "rays_per_launch": rays_rank / launches, "rays_traced_by_this_kernel": rays_rank,
+                "Mray_per_s_of_this_kernel": rays_rank / trace_s / 1e6 if trace_s > 0 else None}
         if valu and valu.get("valu_lane_ops_per_ray") and trace_s > 0:
             ach = valu["valu_lane_ops_per_ray"] * rays_rank / trace_s / 1e12
             roof.update({"achieved": ach, "frac": ach / VALU_PEAK_TLANEOPS, "frac_if_dual_issue": ach / (2 * VALU_PEAK_TLANEOPS),
@@ -221,9 +223,11 @@ def main():
                                  "counters_from); rays and k_trace time are this run's.  frac = (lanes of 64 per VALU instruction) x (share of "
                                  "quad-cycles the VALU issues) x (clock / 2.4 GHz): the share of the chip's VALU lane-slots doing this kernel's work"})
         roof_hbm = {"bound": "hbm", "kernel": "k_trace", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                    "algorithmic_GBps": alg_bytes / trace_s / 1e9 if trace_s > 0 else None,
+                    "algorithmic_GBps": alg_bytes / (trace_s + st.light_ms * 1e-3) / 1e9 if trace_s > 0 else None,
                     "algorithmic_bytes_per_launch": alg_bytes / launches,
-                    "algorithmic_bytes_per_ray": alg_bytes / rays_rank if rays_rank else None}
+                    "algorithmic_bytes_per_ray": alg_bytes / float(st.rays_primary + st.rays_secondary),
+                    "note_algorithmic": "40 B x V + 36 B x T of ALL rays of the step (k_light's included) over k_trace's time alone would overstate: "
+                                        "algorithmic_GBps divides by the device time of both tracing kernels"}
         if hbm and hbm.get("k_trace_hbm_bytes_per_ray") and trace_s > 0:
             b = hbm["k_trace_hbm_bytes_per_ray"] * rays_rank
             roof_hbm.update({"achieved": b / trace_s / 1e9, "frac": b / trace_s / 1e9 / HBM_PEAK_GBS, "traffic": b / launches,
@@ -255,6 +259,15 @@ def main():
             "rays": rays_all,
             "samples": float(vals[5].item()),
             "rays_incl_warmup_this_rank": float(st.rays_primary + st.rays_secondary + st_w.rays_primary + st_w.rays_secondary),
+            "rays_k_trace_incl_warmup_this_rank": float(st.rays_primary + st.rays_secondary - st.rays_inline + st_w.rays_primary
+                                                        + st_w.rays_secondary - st_w.rays_inline),
+            # the step by kernel on this rank: k_light (fused first pass: light samples traced and shaded in one kernel),
+            # k_trace (everything else that is traced), the rest = k_shade / k_arm / gaps
+            "kernels": {"k_light": {"ms_per_step": st.light_ms / max(args.steps, 1), "rays": float(st.rays_inline),
+                                    "Mray_per_s": st.rays_inline / (st.light_ms * 1e-3) / 1e6 if st.light_ms else None},
+                        "k_trace": {"ms_per_step": st.trace_ms / max(args.steps, 1), "rays": rays_rank,
+                                    "Mray_per_s": rays_rank / trace_s / 1e6 if trace_s > 0 else None},
+                        "device_ms_per_step": st.kernel_ms / max(args.steps, 1)},
             "rays_by_call_site": {k[5:]: float(vals[6 + i].item()) for i, k in enumerate(cls_keys)},
             "gather_ms": gather_ms,
             "frame_ok": frame_ok,

@@ -163,6 +163,10 @@ typedef struct jade_stats {
    * (:1383), refraction rays (:1202, 1241) */
   uint64_t rays_shadow, rays_env, rays_indirect, rays_mirror, rays_refract;
   uint64_t host_syncs;     /* HIP: times the host waited for the device inside step/flush; oracle: 0 */
+  /* HIP: rays (of the counts above) that were traced inside the fused first-pass kernel k_light, not by k_trace:
+   * trace_ms / trace_launches cover the other rays only.  Oracle: 0. */
+  uint64_t rays_inline;
+  double light_ms;         /* HIP: device time of k_light (HIP events), summed over launches; oracle: 0 */
 } jade_stats;
 
 typedef struct jade_scene jade_scene; /* opaque */

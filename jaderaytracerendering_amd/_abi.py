@@ -71,6 +71,7 @@ class Stats(C.Structure):
         ("trace_ms", C.c_double), ("trace_launches", C.c_uint64),
         ("rays_shadow", C.c_uint64), ("rays_env", C.c_uint64), ("rays_indirect", C.c_uint64),
         ("rays_mirror", C.c_uint64), ("rays_refract", C.c_uint64), ("host_syncs", C.c_uint64),
+        ("rays_inline", C.c_uint64), ("light_ms", C.c_double),
     ]
 
     def as_dict(self):

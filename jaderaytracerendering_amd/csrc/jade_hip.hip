@@ -822,6 +822,289 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// k_light: the first pass of a step, fused.  Most samples of most frames are LIGHT: the camera ray misses (sky), or it
+// meets an emitter, or a pure mirror whose reflected ray then misses (the floor).  Run as shade / trace passes, such a
+// sample crosses memory six times (camera ray out, its result back, mirror ray out, ...) for a handful of arithmetic:
+// k_shade_lean was bound by those bytes (3.5 TB/s of HBM, 15 % of a step) and the rays' records by their round trip
+// through the queue.  Here a record keeps its light samples in registers: it generates the camera ray, traces it IN
+// THIS KERNEL (the same node / triangle steps as k_trace, a wave's rays side by side until all have ended - camera and
+// floor-mirror rays of neighbouring pixels are coherent), folds the result in, follows a pure mirror, adds the finished
+// sample to its partial sum and starts the next one, until it runs out of samples or meets a surface the light path
+// cannot shade (jade, diffuse, glass).  Then it parks the path exactly where k_shade_lean would have (ST_VERTEX, context
+// stored) and hands the record to k_shade through the same list.  Statements, draw order and sums are those of
+// shade_record<true> + k_trace, so every bit of the result is the same (test_result_independent_of_shade_schedule).
+// ---------------------------------------------------------------------------------------------------------------
+#ifndef JADE_LIGHT_WAVES
+#define JADE_LIGHT_WAVES 4
+#endif
+__global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_LIGHT_WAVES) void k_light(DevScene S, PathState P, RenderConst R, const int32_t* tile_ids,
+                                                                            uint32_t target_spp, uint32_t* heavy_out, QueueCtl* qc,
+                                                                            uint32_t* spill, DevCounters* ctr) {
+  __shared__ uint32_t lds_cols[JADE_CTX_WORDS * JADE_TRACE_BLOCK];
+  __shared__ uint32_t sh_def[JADE_TRACE_BLOCK / 64], sh_base;
+  __shared__ uint32_t sh_ctr[JADE_TRACE_BLOCK / 64][8];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  LdsStack stk;
+  stk.lds = lds_cols + threadIdx.x;
+  stk.spill = spill + (blockIdx.x * blockDim.x + threadIdx.x);
+  stk.stride_spill = gridDim.x * blockDim.x;
+  stk.top = nullptr;
+  stk.top_k = 0;
+#if JADE_LDS_TOP_NODES > 0
+  __shared__ float4 lds_top[4 * JADE_LDS_TOP_NODES];
+  {
+    const uint32_t k = S.top_k;
+    for (uint32_t i = threadIdx.x; i < 4u * k; i += JADE_TRACE_BLOCK) lds_top[(i & 3u) * k + (i >> 2)] = S.nodes[i];
+    __syncthreads();
+    stk.top = lds_top;
+    stk.top_k = k;
+  }
+#endif
+  const int npix = P.npix;
+  const size_t sn = (size_t)JADE_SAMPLE_LANES * (size_t)P.npx;
+  uint32_t vcnt = 0, tcnt = 0, n_mirror = 0;
+  ShadeCtx c;
+  c.n_emit_rays = 0;
+  c.c_primary = c.c_shadow = c.c_shaded = c.c_samples = c.c_cls = 0;
+  // records are dealt to the resident blocks in chunks of one block (a persistent grid: the LDS copy of the tree top is
+  // made once per block, not once per 256 records)
+  for (size_t base = (size_t)blockIdx.x * JADE_TRACE_BLOCK; base < (size_t)npix; base += (size_t)gridDim.x * JADE_TRACE_BLOCK) {
+    const size_t p64 = base + threadIdx.x;
+    const bool have = p64 < (size_t)npix;
+    const int p = have ? (int)p64 : 0;
+    const uint32_t word = P.stage[p];
+    uint32_t st = have ? (word & 255u) : (uint32_t)ST_INVALID;
+    const uint32_t rec_m = (uint32_t)p / (uint32_t)P.npx;
+    const int home_pix = (int)((uint32_t)p - rec_m * (uint32_t)P.npx);
+    const int tid0 = tile_ids[home_pix >> 8];
+    uint32_t done = P.done[p];
+    bool defer = false;  // hand the record to k_shade
+    // a record that is in the middle of a path (carried over from the last step, its rays traced and their results
+    // waiting in memory) goes to k_shade untouched, as k_shade_lean does; an idle one is this kernel's to run
+    bool mine = st == ST_IDLE;
+    const bool untouched = have && st != ST_IDLE && st != ST_INVALID;
+    if (untouched) defer = true;
+    c.rng = P.rng[p];
+    c.depth = 0;
+    c.flags = 0;
+    c.thr = jv(1, 1, 1);
+    c.acc = jv(0, 0, 0);
+    c.le = jv(0, 0, 0);
+    c.obj = 0;
+    c.src = jv(0, 0, 0);
+    c.out = jv(0, 0, 0);
+    RegPx rp;
+    rp.d = jv(0, 0, 0);
+    rp.o = jv(0, 0, 0);
+    rp.hp = jv(0, 0, 0);
+    rp.h = -1;
+    rp.sk = -1;
+    bool finished = false;
+    jvec3 color = jv(0, 0, 0), l_final = jv(0, 0, 0);
+    // A lane is tracing (`active`), or waits to be shaded: its ray's result folded in and the next ray set up.  Shading
+    // runs for >= JADE_REFILL_MIN waiting lanes at a time (or when nothing is being traced): it is k_trace's refill, with
+    // the next ray coming from the lane's own path instead of from a queue.
+    bool active = false;   // a ray in flight
+    bool pending = false;  // its result has not been folded in yet
+    RayState r;
+    r.cur = JADE_REF_NONE;
+    r.leaf = 0;
+    r.ctl = 0;
+    r.skipx = 0;
+    r.od.a = r.od.b = r.od.c = f2{0.0f, 0.0f};
+    for (;;) {
+      const unsigned long long tracing = __ballot(active);
+      const int n_wait = __popcll(__ballot(mine && !active));
+      if (tracing == 0ull && n_wait == 0) break;  // every lane is out of samples or parked
+      if (n_wait >= JADE_REFILL_MIN || tracing == 0ull) {
+        if (mine && !active) {
+          // ---- fold the result in (shade_record's part (a))
+          if (pending) {
+            pending = false;
+            rp.h = ray_best_index(stk);
+            if (rp.h >= 0) rp.hp = ray_hit_point(stk);
+            if (st == ST_PRIMARY) {
+              if (rp.h < 0) {
+                color = sample_hdr(S, rp.d);  // PathTrace.cu:1443-1445
+                finished = true;
+              } else {
+                c.le = V3(S.tris[rp.h].emissive);
+                c.thr = jv(1, 1, 1);
+                c.acc = jv(0, 0, 0);
+                c.depth = 0;
+                c.obj = rp.h;
+                c.src = rp.hp;
+                c.out = jv_neg(rp.d);
+                st = ST_VERTEX;
+              }
+            } else {  // ST_MIRROR
+              c.stage = ST_MIRROR;
+              const int rr = consume_mirror(S, rp, c, &l_final);
+              if (rr == CONSUME_VERTEX) {
+                st = ST_VERTEX;
+              } else {
+                color = jv_add(c.le, jv_add(c.acc, jv_mul(c.thr, l_final)));
+                finished = true;
+              }
+            }
+          }
+          // ---- advance until this lane has a ray to trace, is out of samples, or parks (part (b))
+          bool ray = false;
+          for (;;) {
+            if (finished) {
+              const NextSample cs = next_sample_mh(P, rec_m, (uint32_t)home_pix, done);  // the sample that just ended
+              const size_t si = (size_t)(cs.sidx % JADE_SAMPLE_LANES) * (size_t)P.npx + (size_t)cs.pixel;
+              st3w(P.sum, sn, si, jv_add(ld3w(P.sum, sn, si), color));
+              done += 1;
+              c.c_samples += 1;
+              finished = false;
+              st = ST_IDLE;
+            }
+            if (st == ST_VERTEX) {
+              if (!lean_can_shade(&S.tris[c.obj])) {  // jade / diffuse / glass: k_shade continues from here
+                defer = true;
+                mine = false;
+                break;
+              }
+              if (begin_bounce_lean(S, rp, c, &l_final)) {  // the mirror ray is in rp
+                n_mirror += 1;
+                st = ST_MIRROR;
+                ray = true;
+                break;
+              }
+              color = jv_add(c.le, jv_add(c.acc, jv_mul(c.thr, l_final)));
+              finished = true;
+              continue;
+            }
+            // ST_IDLE: the next sample of this record; samples of out-of-image pixels (edge tiles) are skipped
+            int x, y;
+            NextSample ns = next_sample_mh(P, rec_m, (uint32_t)home_pix, done);
+            while (ns.sidx < target_spp && !pixel_xy_t(R, ns.pixel == home_pix ? tid0 : tile_ids[ns.pixel >> 8], ns.pixel, &x, &y)) {
+              done += 1;
+              ns = next_sample_mh(P, rec_m, (uint32_t)home_pix, done);
+            }
+            if (ns.sidx >= target_spp) {  // nothing left for this record in this step
+              mine = false;
+              break;
+            }
+            // camera ray, PathTrace.cu:1428-1437 (the statements of shade_record)
+            c.rng = jade_rng_seed((uint32_t)x, (uint32_t)y, R.frame + ns.sidx);
+            float fx = (float)x + jade_rand(&c.rng);
+            double lo = -1.0 + R.two_over_w * ((double)fx - 0.5);
+            float left_offset = (float)(lo * R.aspect);
+            float fy = (float)y + jade_rand(&c.rng);
+            float up_offset = (float)(-1.0 + R.two_over_h * ((double)fy - 0.5));
+            jvec3 dir = jade_transform(jv(left_offset, up_offset, -1.5f), 0.0f, R.cam);
+            dir = jv_normalize(dir);
+            rp.set_origin(jv(P.eye[0], P.eye[1], P.eye[2]), JADE_SKIP_CAMERA);
+            rp.set_dir(0, dir);
+            c.c_primary += 1;
+            c.depth = 0;
+            c.flags = 0;
+            st = ST_PRIMARY;
+            ray = true;
+            break;
+          }
+          if (ray) {
+            ray_begin(r, stk, S, rp.o, rp.d, rp.sk);
+            vcnt += 1;  // the root record
+            active = true;
+            pending = true;
+          }
+        }
+        if (__ballot(active) == 0ull) continue;  // (every lane went out or parked: the loop ends at its top)
+      }
+      // ---- one kind of work for every tracing lane that has some (k_trace's inner loop: hitBVH, PathTrace.cu:795-859)
+      {
+        const bool cw = active && ray_can_walk(r), ct = active && ray_can_test(r);
+        const int nw = __popcll(__ballot(cw)), nt = __popcll(__ballot(ct));
+        if (JADE_COST_TRI * nw >= JADE_COST_NODE * nt) {
+          if (__ballot(active && (int32_t)r.skipx < 0) != 0ull) {
+#pragma nounroll
+            for (int rep = 0; rep < JADE_STEPS_PER_PICK; ++rep)
+              if (active && ray_can_walk(r)) ray_step_node_s<true>(r, S, stk, vcnt);
+          } else {
+#pragma nounroll
+            for (int rep = 0; rep < JADE_STEPS_PER_PICK; ++rep)
+              if (active && ray_can_walk(r)) ray_step_node_s<false>(r, S, stk, vcnt);
+          }
+        } else {
+#pragma nounroll
+          for (int rep = 0; rep < JADE_STEPS_PER_PICK; ++rep)
+            if (active && ray_can_test(r)) ray_step_tri_s(r, S, stk, tcnt);
+        }
+        if (active && ray_done(r)) active = false;  // its result stays in the LDS column until the lane is shaded
+      }
+    }
+    // ---- store what the next kernel needs
+    if (have && st != ST_INVALID && !untouched) {  // (a carried-over record was not touched)
+      P.rng[p] = c.rng;
+      P.done[p] = done;
+      if (st == ST_VERTEX) {  // parked: the path context, as shade_record stores it for this stage
+        P.stage[p] = ST_VERTEX | (c.depth << 8) | (c.flags << 16);
+        P.obj[p] = c.obj;
+        if (c.depth != 0) {
+          st3(P.thr, npix, p, c.thr);
+          st3(P.acc, npix, p, c.acc);
+        }
+        st3(P.le, npix, p, c.le);
+        st3(P.src, npix, p, c.src);
+        st3(P.out, npix, p, c.out);
+      } else {
+        P.stage[p] = ST_IDLE;
+      }
+    }
+    // ---- hand-over list: wave scan, one atomic per block
+    {
+      const unsigned long long dm = __ballot(defer);
+      const uint32_t doff = (uint32_t)__popcll(dm & ((1ull << lane) - 1ull));
+      if (lane == 0) sh_def[w] = (uint32_t)__popcll(dm);
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        uint32_t td = 0;
+        for (int i = 0; i < JADE_TRACE_BLOCK / 64; ++i) td += sh_def[i];
+        sh_base = td ? atomicAdd(&qc->heavy, td) : 0u;
+      }
+      __syncthreads();
+      if (defer) {
+        uint32_t wd = sh_base + doff;
+        for (int i = 0; i < w; ++i) wd += sh_def[i];
+        heavy_out[wd] = (uint32_t)p;
+      }
+      __syncthreads();  // sh_def / sh_base are reused by the next chunk
+    }
+  }
+  // ---- work counters: per wave into LDS, then one set of atomics per block (as shade_tail), and V / T as k_trace
+  {
+    const uint32_t s0 = (uint32_t)wave_sum_u32(c.c_primary), s2 = (uint32_t)wave_sum_u32(c.c_shaded), s3 = (uint32_t)wave_sum_u32(c.c_samples);
+    const unsigned long long s6 = wave_sum_u32(n_mirror);
+    const unsigned long long sv = wave_sum_u32(vcnt), stt = wave_sum_u32(tcnt);
+    if (lane == 0) {
+      sh_ctr[w][0] = s0;
+      sh_ctr[w][1] = 0;
+      sh_ctr[w][2] = s2;
+      sh_ctr[w][3] = s3;
+      sh_ctr[w][4] = 0;
+      sh_ctr[w][5] = 0;
+      sh_ctr[w][6] = (uint32_t)s6;
+      sh_ctr[w][7] = 0;
+      DevCounters* cs = ctr + (blockIdx.x % JADE_CTR_SHARDS);
+      if (sv) atomicAdd(&cs->nodes_visited, sv);
+      if (stt) atomicAdd(&cs->tris_tested, stt);
+      if (s0 + s6) atomicAdd(&cs->rays_inline, (unsigned long long)s0 + s6);  // every camera and mirror ray of this kernel was traced here
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+      unsigned long long t = 0;
+      for (int i = 0; i < JADE_TRACE_BLOCK / 64; ++i) t += sh_ctr[i][threadIdx.x];
+      DevCounters* cs = ctr + (blockIdx.x % JADE_CTR_SHARDS);
+      const int i = (int)threadIdx.x, wordi = i < 2 ? i : i < 4 ? i + 2 : i + 4;
+      if (t) atomicAdd(reinterpret_cast<unsigned long long*>(cs) + wordi, t);
+    }
+  }
+}
+
 // ACESToneMapping + gamma + BGR pack, PathTrace.cu:680-682, 1457-1473.
 __global__ void k_resolve(PathState P, RenderConst R, const int32_t* tile_ids, float inv_spp, int tonemap, float limit,
                           float* out_rgb, uint8_t* out_bgr) {
@@ -924,13 +1207,18 @@ struct jade_scene {
   DevBuf b_state, b_tiles, b_queue, b_active[2], b_ctl, b_ctr, b_spill, b_out_rgb, b_out_bgr;
   std::vector<int32_t> tile_ids;
   int trace_blocks = 0;
+  int light_blocks = 0;       // persistent grid of k_light
   int64_t spp_done = 0;
   bool tail_pending = false;  // the last step left its longest paths unfinished (jade_render_flush)
   hipEvent_t ev[7] = {};      // run_passes' timing events, made once (ev0, ev1, ta, tb, sa, sb, sm)
   hipEvent_t ev_resolve = nullptr;  // jade_render_resolve_tiles_device: caller's stream -> scene stream
   uint64_t host_syncs = 0;    // host waits inside step/flush since the last advance() reported them
+  double light_ms = 0;        // k_light device time since then
+  hipEvent_t ev_light[2] = {};
   ~jade_scene() {
     if (ev_resolve) (void)hipEventDestroy(ev_resolve);
+    for (hipEvent_t e : ev_light)
+      if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev)
       if (e) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
@@ -1227,6 +1515,11 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
   }
   if (getenv("JADE_LOG_PASSES")) fprintf(stderr, "[jade] k_trace: %d blocks of %d threads per CU, %d CUs\n", per_cu, JADE_TRACE_BLOCK, prop.multiProcessorCount);
   s->trace_blocks = prop.multiProcessorCount * per_cu;
+  int light_cu = 0;
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&light_cu, k_light, JADE_TRACE_BLOCK, 0);
+  if (light_cu < 1) light_cu = 1;
+  if (light_cu > per_cu) light_cu = per_cu;  // the stack spill area is sized for the k_trace grid
+  s->light_blocks = prop.multiProcessorCount * light_cu;
   *out = s;
   return JADE_OK;
 }
@@ -1366,6 +1659,7 @@ static hipError_t sum_counters(jade_scene* s, DevCounters* out) {
     out->shaded_hits += c.shaded_hits; out->samples += c.samples;
     out->rays_env += c.rays_env; out->rays_indirect += c.rays_indirect;
     out->rays_mirror += c.rays_mirror; out->rays_refract += c.rays_refract;
+    out->rays_inline += c.rays_inline;
     out->pad[0] += c.pad[0]; out->pad[1] += c.pad[1];
   }
 #if JADE_TRACE_PROFILE
@@ -1405,7 +1699,10 @@ static int run_passes(jade_scene* s, uint32_t target_spp, bool may_carry, double
   // (record order, no list) followed by k_shade over what it handed over; below that, k_shade alone
   // over the active list, which k_arm rebuilds once at the switch.  JADE_SHADE_SPLIT=0: always the list.
   const bool split_ok = !(getenv("JADE_SHADE_SPLIT") && atoi(getenv("JADE_SHADE_SPLIT")) == 0);
+  // JADE_FUSED=0: the first pass as shade / trace passes too (k_shade_lean), the schedule before k_light existed
+  const bool fused = split_ok && !(getenv("JADE_FUSED") && atoi(getenv("JADE_FUSED")) == 0);
   bool have_list = true;  // b_active[cur] lists the active records
+  bool light_timed = false;
   float shade_ms = 0, lean_ms = 0;
   while (n_active) {
     const bool lean_mode = split_ok && (uint64_t)n_active * 4 >= (uint64_t)npix;
@@ -1419,7 +1716,22 @@ static int run_passes(jade_scene* s, uint32_t target_spp, bool may_carry, double
     HIP_TRY(hipMemsetAsync(qc, 0, 16, s->stream));  // count, active, next, heavy
     if (log_passes) HIP_TRY(hipEventRecord(sa, s->stream));
     const unsigned nb = (n_active + JADE_SHADE_BLOCK - 1) / JADE_SHADE_BLOCK;
-    if (lean_mode) {
+    if (lean_mode && fused && pass_no == 0) {
+      // the step's first pass, fused: light samples run to completion inside k_light, everything else is handed over
+      for (hipEvent_t& e : s->ev_light)
+        if (!e) HIP_TRY(hipEventCreate(&e));
+      HIP_TRY(hipEventRecord(s->ev_light[0], s->stream));
+      light_timed = true;
+      hipLaunchKernelGGL(k_light, dim3((unsigned)std::min<size_t>((size_t)s->light_blocks, ((size_t)npix + JADE_TRACE_BLOCK - 1) / JADE_TRACE_BLOCK)),
+                         dim3(JADE_TRACE_BLOCK), 0, s->stream, s->dev, s->ps, s->rc, s->b_tiles.as<int32_t>(), target_spp,
+                         s->b_active[1].as<uint32_t>(), qc, s->b_spill.as<uint32_t>(), s->b_ctr.as<DevCounters>());
+      HIP_TRY(hipEventRecord(s->ev_light[1], s->stream));
+      if (log_passes) HIP_TRY(hipEventRecord(sm, s->stream));
+      hipLaunchKernelGGL(k_shade, dim3(nb), dim3(JADE_SHADE_BLOCK), 0, s->stream, s->dev, s->ps, s->rc, s->b_tiles.as<int32_t>(),
+                         target_spp, s->b_active[1].as<uint32_t>(), 0u, &qc->heavy, (uint32_t*)nullptr, s->b_queue.as<uint32_t>(), qc,
+                         s->b_ctr.as<DevCounters>());
+      have_list = false;
+    } else if (lean_mode) {
       // b_active[1] carries the hand-over list; no active list is kept in this mode
       hipLaunchKernelGGL(k_shade_lean, dim3((unsigned)((npix + JADE_LEAN_BLOCK - 1) / JADE_LEAN_BLOCK)), dim3(JADE_LEAN_BLOCK), 0,
                          s->stream, s->dev, s->ps, s->rc, s->b_tiles.as<int32_t>(), target_spp, s->b_active[1].as<uint32_t>(),
@@ -1442,6 +1754,12 @@ static int run_passes(jade_scene* s, uint32_t target_spp, bool may_carry, double
     HIP_TRY(hipMemcpyAsync(host_ctl, qc, 12, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
   s->host_syncs += 1;
+    if (light_timed) {  // (the stream was just synchronised)
+      float lt = 0;
+      HIP_TRY(hipEventElapsedTime(&lt, s->ev_light[0], s->ev_light[1]));
+      s->light_ms += lt;
+      light_timed = false;
+    }
     if (log_passes) {
       HIP_TRY(hipEventElapsedTime(&shade_ms, sa, sb));
       HIP_TRY(hipEventElapsedTime(&lean_ms, sa, sm));
@@ -1535,6 +1853,8 @@ static int advance(jade_scene* s, int64_t from0, bool may_carry, jade_stats* st)
     st->rays_indirect += c.rays_indirect;
     st->rays_mirror += c.rays_mirror;
     st->rays_refract += c.rays_refract;
+    st->rays_inline += c.rays_inline;
+    st->light_ms += s->light_ms;
     st->nodes_visited += c.nodes_visited;
     st->tris_tested += c.tris_tested;
     st->shaded_hits += c.shaded_hits;
@@ -1545,6 +1865,7 @@ static int advance(jade_scene* s, int64_t from0, bool may_carry, jade_stats* st)
     st->host_syncs += s->host_syncs;
   }
   s->host_syncs = 0;
+  s->light_ms = 0;
   return JADE_OK;
 }
 

@@ -125,6 +125,27 @@ struct Px {
   }
   __device__ int hit(int k) const { return P.hit[(size_t)k * P.npix + p]; }
   __device__ void set_hit(int k, int v) const { P.hit[(size_t)k * P.npix + p] = v; }
+  // origin shared by the record's pending rays + the triangle they leave
+  __device__ void set_origin(jvec3 o, int skip) const {
+    st3(P.org, P.npix, p, o);
+    P.skip[p] = skip;
+  }
+};
+
+// The same view held in registers: k_light traces a record's single ray (camera or mirror) in the kernel that shades
+// it, so the ray and its result never travel through memory.  Slot 0 only.
+struct RegPx {
+  jvec3 d, o, hp;
+  int h, sk;
+  __device__ jvec3 dir(int) const { return d; }
+  __device__ void set_dir(int, jvec3 v) { d = v; }
+  __device__ jvec3 hpt(int) const { return hp; }
+  __device__ int hit(int) const { return h; }
+  __device__ void set_hit(int, int v) { h = v; }
+  __device__ void set_origin(jvec3 org, int skip) {
+    o = org;
+    sk = skip;
+  }
 };
 
 struct ShadeCtx {
@@ -151,10 +172,10 @@ static __device__ __forceinline__ bool path_push(ShadeCtx& c, jvec3 dirv, jvec3 
 
 // The mirror branch of the bounce loop (PathTrace.cu:1365-1405): RR, then the reflected ray.
 // Shared by the full shading kernel and the lean one (k_shade<true>).
-static __device__ __forceinline__ bool bounce_mirror(const Px& px, ShadeCtx& c, const jade_triangle* ot, jvec3 obj_emissive, jvec3 n,
+template <class PX>
+static __device__ __forceinline__ bool bounce_mirror(PX& px, ShadeCtx& c, const jade_triangle* ot, jvec3 obj_emissive, jvec3 n,
                                                      jvec3* l_final) {
   const float RR_F = (float)JADE_RR_RATE_D;
-  const int pix = px.p, npix = px.P.npix;
   jvec3 obj_hit_fr = jv_scale(V3(ot->brdf), (float)(1.0 / JADE_PI_D));
   int k = ot->refract_mode != JADE_NO_REFRACT ? 2 : 1;
   if (obj_emissive.x > 1.5e-4f || obj_emissive.y > 1.5e-4f || obj_emissive.x > 1.5e-4f) {
@@ -164,8 +185,7 @@ static __device__ __forceinline__ bool bounce_mirror(const Px& px, ShadeCtx& c, 
   float rr_result = jade_rand(&c.rng);
   if (!(rr_result < RR_F)) return false;
   jvec3 refl = jv_sub(jv_scale(n, 2 * jv_dot(c.out, n)), c.out);
-  st3(px.P.org, npix, pix, c.src);
-  px.P.skip[pix] = c.obj;
+  px.set_origin(c.src, c.obj);
   px.set_dir(0, refl);
   px.set_hit(0, -1);
   c.n_emit_rays++;
@@ -183,7 +203,8 @@ static __device__ __forceinline__ bool lean_can_shade(const jade_triangle* ot) {
 
 // begin_bounce restricted to those two cases: the same statements in the same order
 // (emissive test :916-920, the select draw :924, then the mirror branch).
-static __device__ bool begin_bounce_lean(const DevScene& S, const Px& px, ShadeCtx& c, jvec3* l_final) {
+template <class PX>
+static __device__ bool begin_bounce_lean(const DevScene& S, PX& px, ShadeCtx& c, jvec3* l_final) {
   const jade_triangle* ot = &S.tris[c.obj];
   c.c_shaded += 1;
   jvec3 obj_emissive = V3(ot->emissive);
@@ -375,7 +396,8 @@ diffuse_like:
 enum { CONSUME_VERTEX = 0, CONSUME_END = 1, CONSUME_ZERO = 2, CONSUME_EMITTED = 3 };
 
 // Result of the mirror ray (PathTrace.cu:1383-1398).  Shared by both shading kernels.
-static __device__ __forceinline__ int consume_mirror(const DevScene& S, const Px& px, ShadeCtx& c, jvec3* l_final) {
+template <class PX>
+static __device__ __forceinline__ int consume_mirror(const DevScene& S, const PX& px, ShadeCtx& c, jvec3* l_final) {
   const jade_triangle* ot = &S.tris[c.obj];
   const int k = ot->refract_mode != JADE_NO_REFRACT ? 2 : 1;
   const jvec3 obj_hit_fr = jv_scale(V3(ot->brdf), (float)(1.0 / JADE_PI_D));

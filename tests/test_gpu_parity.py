@@ -198,16 +198,17 @@ def test_result_independent_of_paths_in_flight(hip, monkeypatch):
 
 
 def test_result_independent_of_shade_schedule(hip, monkeypatch):
-    """A pass is either k_shade_lean over all records + k_shade over what it hands over, or k_shade
-    alone over the active list (the backend switches on the share of active records):
-    JADE_SHADE_SPLIT=0 forces the second form, and every bit of the result must be the same."""
+    """A step's first pass is the fused k_light (light samples traced and shaded in one kernel) + k_shade over what it
+    hands over; JADE_FUSED=0 runs it as k_shade_lean + k_shade + k_trace passes instead, and JADE_SHADE_SPLIT=0 as k_shade
+    alone over the active list (what later passes use anyway).  Every bit of the result must be the same."""
     for name, spp in (("tinyjade", 24), ("C1", 6)):
         hs, cfg = config_scene(name)
         p = B.params_from_config(cfg, spp=spp)
         p.width, p.height = 40, 36
         ref = None
-        for split in ("1", "0"):
+        for split, fused in (("1", "1"), ("1", "0"), ("0", "1")):
             monkeypatch.setenv("JADE_SHADE_SPLIT", split)
+            monkeypatch.setenv("JADE_FUSED", fused)   # the step's first pass as the fused k_light, or as k_shade_lean + k_trace
             with hip.scene(hs) as sc:
                 rgb, bgr, st = sc.render(p)
             if ref is None:

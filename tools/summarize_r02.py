@@ -22,7 +22,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 O = os.path.join(ROOT, "gpurun_out", tag)
-KERNELS = ("k_trace", "k_shade", "k_shade_lean", "k_arm", "k_resolve", "k_init")
+KERNELS = ("k_trace", "k_light", "k_shade", "k_shade_lean", "k_arm", "k_resolve", "k_init")
 N_CU, N_SIMD = 256, 1024
 VALU_PEAK_LANE_OPS = N_SIMD * 16 * 2.4e9  # one wave64 VALU instruction per SIMD per 4 clocks (bench.py, VALU_PEAK_TLANEOPS)
 
@@ -113,7 +113,7 @@ def cut(pre, red, label, command):
             rl = b["roofline"]
             share = rl["launches"] / max(rl.get("launches_incl_warmup", rl["launches"]), 1)
             kt["note"] = "counters cover every launch of the process (warm-up included); per-ray figures use all rays of the process"
-            rays_all = b.get("rays_incl_warmup_this_rank") or b["rays"] / b["steps"] * (b["steps"] + b["warmup"])
+            rays_all = b.get("rays_k_trace_incl_warmup_this_rank") or b.get("rays_incl_warmup_this_rank") or b["rays"] / b["steps"] * (b["steps"] + b["warmup"])
             kt["valu_lane_ops_per_ray"] = kt["lane_ops"] / rays_all
             kt["valu_wave_insts_per_ray"] = kt["SQ_INSTS_VALU"] / rays_all
             kt["timed_launch_share"] = share
@@ -140,7 +140,7 @@ def cut(pre, red, label, command):
             summ["k_trace_hbm_GBps_profiled"] = hbm / secs / 1e9
             summ["k_trace_l2_hit_rate"] = t["TCC_HIT_sum"]["sum"] / (t["TCC_HIT_sum"]["sum"] + t["TCC_MISS_sum"]["sum"])
             if b.get("roofline"):
-                rays_all = b.get("rays_incl_warmup_this_rank") or b["rays"] / b["steps"] * (b["steps"] + b["warmup"])
+                rays_all = b.get("rays_k_trace_incl_warmup_this_rank") or b.get("rays_incl_warmup_this_rank") or b["rays"] / b["steps"] * (b["steps"] + b["warmup"])
                 summ["k_trace_hbm_bytes_per_ray"] = hbm / rays_all
                 summ["rays_of_profiled_process"] = rays_all
         for k in ("k_shade", "k_shade_lean"):
