@@ -473,6 +473,9 @@ __global__ __launch_bounds__(JADE_LEAN_BLOCK) void k_shade_lean(DevScene S, Path
 #ifndef JADE_STRAIGHT
 #define JADE_STRAIGHT 1 /* branch-free node / triangle steps (jade_trace.h) */
 #endif
+#if JADE_PAIR && !JADE_STRAIGHT
+#error "JADE_PAIR (pair vertex records) needs the straight-line steps: build with -DJADE_PAIR=0 -DJADE_STRAIGHT=0 for the branchy form"
+#endif
 #ifndef JADE_TRACE_NT
 #define JADE_TRACE_NT 1 /* k_trace reads and writes the ray records with non-temporal hints */
 #endif
@@ -496,7 +499,7 @@ __global__ __launch_bounds__(JADE_LEAN_BLOCK) void k_shade_lean(DevScene S, Path
 #define JADE_COST_TRI 120  /* ... and by a triangle-test iteration (k_trace picks the kind per wave iteration) */
 #endif
 #ifndef JADE_TRACE_WAVES
-#define JADE_TRACE_WAVES 1
+#define JADE_TRACE_WAVES 5 /* waves per SIMD the register allocation must leave room for: the pair-packed triangle test wants 104 VGPRs, at 92 (no scratch) a fifth wave fits and k_trace is 8 % faster */
 #endif
 __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(DevScene S, PathState P, const uint32_t* queue, QueueCtl* qc,
                                                            uint32_t* spill, DevCounters* ctr, uint32_t chunk) {
@@ -1425,10 +1428,30 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
     for (int i = 1; i < nN; ++i)
       if (d->nodes[i].n <= 0 && compact[i] < 0) compact[i] = n_internal++;
   }
+#if JADE_PAIR
+  // vertex records hold two consecutive triangles of a leaf each (jade_trace.h): number the pairs leaf by leaf
+  std::vector<uint32_t> pair_first(nN, 0);
+  size_t n_pairs = 0;
+  {
+    std::vector<int> leaves;
+    for (int i = 1; i < nN; ++i)
+      if (d->nodes[i].n > 0) leaves.push_back(i);
+    std::sort(leaves.begin(), leaves.end(), [&](int a, int b) { return d->nodes[a].index < d->nodes[b].index; });
+    for (int i : leaves) {
+      pair_first[i] = (uint32_t)n_pairs;
+      n_pairs += (size_t)(d->nodes[i].n + 1) / 2;
+    }
+    if (n_pairs * 5 >= ((size_t)1 << 27)) return fail(JADE_ERR_UNSUPPORTED, "too many triangle pairs for the 27-bit leaf cursor");
+  }
+#endif
   auto ref_of = [&](int child) -> uint32_t {
     if (child <= 0) return JADE_REF_NONE;
     const jade_bvh_node& c = d->nodes[child];
+#if JADE_PAIR
+    if (c.n > 0) return JADE_REF_LEAF | ((pair_first[child] * 5u) << 4) | (uint32_t)((c.n + 1) / 2);  // bits 4-30: byte offset / 16 of the first pair record
+#else
     if (c.n > 0) return JADE_REF_LEAF | ((uint32_t)c.index * 3u << 4) | (uint32_t)c.n;  // bits 4-30: byte offset of the first vertex record
+#endif
     return (uint32_t)compact[child];
   };
   std::vector<float4> nodes((size_t)4 * std::max(n_internal, 1));
@@ -1445,6 +1468,26 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
     uint32_t refs[4] = {ref_of(nd.left), ref_of(nd.right), 0u, 0u};
     memcpy(&o[3], refs, 16);
   }
+#if JADE_PAIR
+  std::vector<float4> tverts((size_t)5 * std::max<size_t>(n_pairs, 1));
+  for (int i = 1; i < nN; ++i) {
+    const jade_bvh_node& nd = d->nodes[i];
+    for (int k = 0; k < nd.n; k += 2) {
+      const bool has_b = k + 1 < nd.n;
+      const jade_triangle& a = d->triangles[nd.index + k];
+      const jade_triangle& b = d->triangles[nd.index + k + (has_b ? 1 : 0)];  // an odd leaf's last record repeats A
+      float4* o = &tverts[5 * ((size_t)pair_first[i] + (size_t)k / 2)];
+      o[0] = make_float4(a.p1[0], b.p1[0], a.p1[1], b.p1[1]);
+      o[1] = make_float4(a.p1[2], b.p1[2], a.p2[0], b.p2[0]);
+      o[2] = make_float4(a.p2[1], b.p2[1], a.p2[2], b.p2[2]);
+      o[3] = make_float4(a.p3[0], b.p3[0], a.p3[1], b.p3[1]);
+      const uint32_t tag[2] = {(uint32_t)(nd.index + k), has_b ? 1u : 0u};
+      float tagf[2];
+      memcpy(tagf, tag, 8);
+      o[4] = make_float4(a.p3[2], b.p3[2], tagf[0], tagf[1]);
+    }
+  }
+#else
   std::vector<float4> tverts((size_t)3 * d->n_triangles);
   for (int i = 0; i < d->n_triangles; ++i) {
     const jade_triangle& t = d->triangles[i];
@@ -1452,6 +1495,7 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
     tverts[3 * (size_t)i + 1] = make_float4(t.p1[2], t.p2[2], t.p3[0], t.p3[1]);
     tverts[3 * (size_t)i + 2] = make_float4(t.p3[2], 0.0f, 0.0f, 0.0f);
   }
+#endif
 
   jade_scene* s = new (std::nothrow) jade_scene();
   if (!s) return fail(JADE_ERR_NOMEM, "out of memory");

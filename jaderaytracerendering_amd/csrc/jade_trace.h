@@ -51,6 +51,9 @@ struct TraceHit {
 #ifndef JADE_ABLATE_LOAD
 #define JADE_ABLATE_LOAD 0
 #endif
+#ifndef JADE_PAIR
+#define JADE_PAIR 1 /* triangle tests two at a time, packed across the two triangles (pair records, below) */
+#endif
 
 // A lane's column of LDS words, lds[word * JADE_TRACE_BLOCK + tid] (bank-conflict free):
 // words [0, JADE_LDS_STACK) are the traversal stack, the JADE_LDS_STATE words after it hold
@@ -237,7 +240,11 @@ static __device__ __forceinline__ void ray_begin(RayState& r, const LdsStack& st
   r.od.b = f2{o.z, dn.x};
   r.od.c = f2{dn.y, dn.z};
   const bool exact = !(finite_f(inv.x) && finite_f(inv.y) && finite_f(inv.z)) || !finite_f(o.x) || !finite_f(o.y) || !finite_f(o.z);
+#if JADE_PAIR
+  r.skipx = (skip < 0 ? 0x7fffffffu : (uint32_t)skip) | (exact ? 0x80000000u : 0u);  // pair records carry triangle indices
+#else
   r.skipx = (skip < 0 ? 0x7fffffffu : (uint32_t)skip * 48u) | (exact ? 0x80000000u : 0u);
+#endif
   r.ctl = 0;
   r.leaf = 0;
   r.cur = S.root_ref;
@@ -276,8 +283,12 @@ static __device__ __forceinline__ void leaf_queue(RayState& r, const LdsStack& s
 }
 
 static __device__ __forceinline__ int32_t ray_best_index(const LdsStack& stk) {
-  const uint32_t off = lds_get(stk, LW_BEST_INDEX);  // byte offset of the vertex record, or ~0
+  const uint32_t off = lds_get(stk, LW_BEST_INDEX);  // byte offset of the vertex record (JADE_PAIR: the triangle index), or ~0
+#if JADE_PAIR
+  return (int32_t)off;  // ~0 is -1
+#else
   return off == 0xffffffffu ? -1 : (int32_t)(off / 48u);
+#endif
 }
 static __device__ __forceinline__ jvec3 ray_hit_point(const LdsStack& stk) {
   return jv(lds_getf(stk, LW_PX), lds_getf(stk, LW_PY), lds_getf(stk, LW_PZ));
@@ -524,6 +535,7 @@ static __device__ __forceinline__ void ray_step_node_s(RayState& r, const DevSce
   r.ctl = (ctl & ~0xffu) | sp;
 }
 
+#if !JADE_PAIR
 // One triangle of the leaf at the head of the FIFO for a lane with ray_can_test.  tcnt: this lane's count of tests.
 static __device__ __forceinline__ void ray_step_tri_s(RayState& r, const DevScene& S, const LdsStack& stk, uint32_t& tcnt) {
   const uint32_t off = r.leaf & 0x7ffffff0u;
@@ -554,3 +566,108 @@ static __device__ __forceinline__ void ray_step_tri_s(RayState& r, const DevScen
   r.leaf = fin ? (has ? nxt : 0u) : leaf;
   r.ctl = (fin && has) ? ctl2 : ctl;
 }
+
+#endif  // !JADE_PAIR
+
+#if JADE_PAIR
+// ---------------------------------------------------------------------------------------------------------------
+// Two triangles per test.  The triangle test is half of k_trace's instructions on the rays that matter (jade paths:
+// 40 tests per ray), and tri_test above packs only HALF of it: the statements for p1 and p2 share instructions, those
+// for p3 - and the third triple product - run alone.  Two consecutive triangles of a leaf have no such remainder: every
+// statement of hitTriangle (PathTrace.cu:705-754) runs once for triangle A in lane .x and for triangle B in lane .y of a
+// packed instruction (IEEE per component: the values are those of the scalar statements).  The vertex data is laid out
+// for it (jade_scene_create): one 80-B record per pair,
+//   {A.p1x B.p1x A.p1y B.p1y} {A.p1z B.p1z A.p2x B.p2x} {A.p2y B.p2y A.p2z B.p2z} {A.p3x B.p3x A.p3y B.p3y}
+//   {A.p3z B.p3z indexA flags}          flags bit 0: B is a triangle (an odd leaf's last record repeats A and clears it),
+// and a leaf reference is LEAF | 5 * first_pair << 4 | pairs: bits 4-30 are still the byte offset of the next record.
+// A is resolved before B (hitArray's index order, strict "<"), the source triangle is skipped by index in either lane.
+// ---------------------------------------------------------------------------------------------------------------
+static __device__ __forceinline__ f2 f2sel(f2 v, int hi) { return hi ? f2{v.y, v.y} : f2{v.x, v.x}; }
+
+// the part of hitTriangle that runs once the projected origin is inside the projected triangle (:732-747)
+static __device__ __forceinline__ bool tri_hit(jvec3 p1, jvec3 p2, jvec3 p3, jvec3 sa, jvec3 sb, jvec3 sc, jvec3 o, jvec3 dn, float* dist_out,
+                                               jvec3* point_out) {
+  jvec3 eb = jv_sub(sb, sa), ec = jv_sub(sc, sa), q = jv_sub(o, sa);
+  float divider = jade_diffprod(eb.x, ec.y, eb.y, ec.x);
+  float rate_a = jade_diffprod(ec.y, q.x, ec.x, q.y) / divider;
+  float rate_b = jade_fma(eb.x, q.y, (-eb.y) * q.x) / divider;
+  jvec3 P = jv_add(jv_add(p1, jv_scale(jv_sub(p2, p1), rate_a)), jv_scale(jv_sub(p3, p1), rate_b));
+  float distance = jv_dot(jv_sub(P, o), dn);
+  *dist_out = distance;
+  *point_out = P;
+  return distance > 0;
+}
+
+static __device__ __forceinline__ void ray_step_tri_s(RayState& r, const DevScene& S, const LdsStack& stk, uint32_t& tcnt) {
+  const uint32_t off = r.leaf & 0x7ffffff0u;
+  const float4* t0 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.tverts) + off);
+  const float4 q0 = t0[0], q1 = t0[1], q2 = t0[2], q3 = t0[3], q4 = t0[4];
+  const uint32_t leaf = r.leaf + 79u;  // next pair record (5 x 16 B), one pair fewer
+  const uint32_t idx_a = jade_f2u(q4.z), skip = r.skipx & 0x7fffffffu;
+  const bool test_a = idx_a != skip, test_b = (jade_f2u(q4.w) & 1u) != 0 && idx_a + 1u != skip;
+  tcnt += (test_a ? 1u : 0u) + (test_b ? 1u : 0u);
+  const RayOD& od = r.od;
+  // lane .x: triangle A, lane .y: triangle B
+  const f2 p1x = {q0.x, q0.y}, p1y = {q0.z, q0.w}, p1z = {q1.x, q1.y};
+  const f2 p2x = {q1.z, q1.w}, p2y = {q2.x, q2.y}, p2z = {q2.z, q2.w};
+  const f2 p3x = {q3.x, q3.y}, p3y = {q3.z, q3.w}, p3z = {q4.x, q4.y};
+  // s = p - dn * dot(dn, p - o)      (jv_dot: fma(a.z, b.z, fma(a.y, b.y, a.x * b.x)))
+  const f2 t1 = f2fma(OD_DZ(od), p1z - OD_OZ(od), f2fma(OD_DY(od), p1y - OD_OY(od), OD_DX(od) * (p1x - OD_OX(od))));
+  const f2 t2 = f2fma(OD_DZ(od), p2z - OD_OZ(od), f2fma(OD_DY(od), p2y - OD_OY(od), OD_DX(od) * (p2x - OD_OX(od))));
+  const f2 t3 = f2fma(OD_DZ(od), p3z - OD_OZ(od), f2fma(OD_DY(od), p3y - OD_OY(od), OD_DX(od) * (p3x - OD_OX(od))));
+  const f2 sax = p1x - OD_DX(od) * t1, say = p1y - OD_DY(od) * t1, saz = p1z - OD_DZ(od) * t1;
+  const f2 sbx = p2x - OD_DX(od) * t2, sby = p2y - OD_DY(od) * t2, sbz = p2z - OD_DZ(od) * t2;
+  const f2 scx = p3x - OD_DX(od) * t3, scy = p3y - OD_DY(od) * t3, scz = p3z - OD_DZ(od) * t3;
+  // pa = sa - o, ...
+  const f2 pax = sax - OD_OX(od), pay = say - OD_OY(od), paz = saz - OD_OZ(od);
+  const f2 pbx = sbx - OD_OX(od), pby = sby - OD_OY(od), pbz = sbz - OD_OZ(od);
+  const f2 pcx = scx - OD_OX(od), pcy = scy - OD_OY(od), pcz = scz - OD_OZ(od);
+  // mixed(dn, u, v) = dn.x * (u.y v.z - u.z v.y), then fma with the y and z terms   (jv_mixed / jade_diffprod)
+  f2 papb = OD_DX(od) * f2fma(pay, pbz, -(paz * pby));
+  papb = f2fma(OD_DY(od), f2fma(paz, pbx, -(pax * pbz)), papb);
+  papb = f2fma(OD_DZ(od), f2fma(pax, pby, -(pay * pbx)), papb);
+  f2 pbpc = OD_DX(od) * f2fma(pby, pcz, -(pbz * pcy));
+  pbpc = f2fma(OD_DY(od), f2fma(pbz, pcx, -(pbx * pcz)), pbpc);
+  pbpc = f2fma(OD_DZ(od), f2fma(pbx, pcy, -(pby * pcx)), pbpc);
+  f2 pcpa = OD_DX(od) * f2fma(pcy, paz, -(pcz * pay));
+  pcpa = f2fma(OD_DY(od), f2fma(pcz, pax, -(pcx * paz)), pcpa);
+  pcpa = f2fma(OD_DZ(od), f2fma(pcx, pay, -(pcy * pax)), pcpa);
+  const bool in_a = test_a && ((papb.x > 0 && pbpc.x > 0 && pcpa.x > 0) || (papb.x < 0 && pbpc.x < 0 && pcpa.x < 0));
+  const bool in_b = test_b && ((papb.y > 0 && pbpc.y > 0 && pcpa.y > 0) || (papb.y < 0 && pbpc.y < 0 && pcpa.y < 0));
+  if (in_a || in_b) {
+    // Rare (one test in ten, 2 % of the kernel's time): the barycentric solve, the distance and the best hit so far, A before
+    // B (index order, strict "<").  Nothing of the packed test is kept alive for it - the record is read again (it is in L1)
+    // and the triangle's three projections are recomputed with the same statements - because 36 registers held across the
+    // test for this block cost the kernel a wave per SIMD.
+    const jvec3 o = od_o(od), dn = od_dn(od);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (k == 0 ? in_a : in_b) {
+        const float* f = reinterpret_cast<const float*>(t0) + k;  // lane k of every pair
+        const jvec3 p1 = jv(f[0], f[2], f[4]), p2 = jv(f[6], f[8], f[10]), p3 = jv(f[12], f[14], f[16]);
+        const jvec3 sa = jv_sub(p1, jv_scale(dn, jv_dot(dn, jv_sub(p1, o))));
+        const jvec3 sb = jv_sub(p2, jv_scale(dn, jv_dot(dn, jv_sub(p2, o))));
+        const jvec3 sc = jv_sub(p3, jv_scale(dn, jv_dot(dn, jv_sub(p3, o))));
+        float dist;
+        jvec3 P;
+        if (tri_hit(p1, p2, p3, sa, sb, sc, o, dn, &dist, &P) && dist < lds_getf(stk, LW_BEST_DIST)) {
+          lds_putf(stk, LW_BEST_DIST, dist);
+          lds_put(stk, LW_BEST_INDEX, idx_a + (uint32_t)k);
+          lds_putf(stk, LW_PX, P.x);
+          lds_putf(stk, LW_PY, P.y);
+          lds_putf(stk, LW_PZ, P.z);
+        }
+      }
+    }
+  }
+  // leaf finished: the next one from the FIFO, if any
+  const bool fin = (leaf & 15u) == 0;
+  const uint32_t ctl = r.ctl;
+  const bool has = ((ctl >> 16) & 0xffu) != 0;
+  const uint32_t head = (ctl >> 8) & 0xffu;
+  const uint32_t nxt = lds_get_w(stk, (uint32_t)LW_FIFO + (head & (JADE_LDS_FIFO - 1)));
+  const uint32_t ctl2 = (ctl & 0xffff00ffu) - (1u << 16) + (((head + 1u) & (JADE_LDS_FIFO - 1)) << 8);
+  r.leaf = fin ? (has ? nxt : 0u) : leaf;
+  r.ctl = (fin && has) ? ctl2 : ctl;
+}
+#endif  // JADE_PAIR
