@@ -631,7 +631,9 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
       w.skipx = selB ? B.r.skipx : A.r.skipx;
       w.cur = selB ? B.r.cur : A.r.cur;
       w.leaf = selB ? B.r.leaf : A.r.leaf;
-      w.ctl = selB ? B.r.ctl : A.r.ctl;
+      w.sp = selB ? B.r.sp : A.r.sp;
+      w.fw = selB ? B.r.fw : A.r.fw;
+      w.fr = selB ? B.r.fr : A.r.fr;
       LdsStack wk = stkA;
       wk.lds = selB ? stkB.lds : stkA.lds;
       wk.spill = selB ? stkB.spill : stkA.spill;
@@ -665,11 +667,15 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
         if (selB) {
           B.r.cur = w.cur;
           B.r.leaf = w.leaf;
-          B.r.ctl = w.ctl;
+          B.r.sp = w.sp;
+          B.r.fw = w.fw;
+          B.r.fr = w.fr;
         } else {
           A.r.cur = w.cur;
           A.r.leaf = w.leaf;
-          A.r.ctl = w.ctl;
+          A.r.sp = w.sp;
+          A.r.fw = w.fw;
+          A.r.fr = w.fr;
         }
       }
       if (A.active && ray_done(A.r)) {
@@ -913,7 +919,7 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_LIGHT_WAVES) void k_light(De
     RayState r;
     r.cur = JADE_REF_NONE;
     r.leaf = 0;
-    r.ctl = 0;
+    r.sp = r.fw = r.fr = 0;
     r.skipx = 0;
     r.od.a = r.od.b = r.od.c = f2{0.0f, 0.0f};
     for (;;) {

@@ -228,10 +228,12 @@ struct RayState {
   uint32_t skipx;  // bit 31: a component of o or 1/d is not finite (NaN-faithful slab needed); bits 0-30: 48 * source triangle, 0x7fffffff = none
   uint32_t cur;    // node walk: internal-node ref, a leaf ref not yet queued, or JADE_REF_NONE = walk finished
   uint32_t leaf;   // triangle tests: cursor of the leaf being tested, 0 = none (then the FIFO is empty too)
-  uint32_t ctl;    // bits 0-7 stack pointer, 8-15 FIFO head, 16-23 FIFO count
+  // (one word used to pack these three: unpacking and repacking it was a dozen instructions per step of a VALU-bound kernel)
+  uint32_t sp;     // stack pointer
+  uint32_t fw, fr; // leaf FIFO: cursors written / read so far (slot = counter & (JADE_LDS_FIFO - 1))
 };
-#define RS_SP(r) ((r).ctl & 0xffu)
-#define RS_FIFO_N(r) (((r).ctl >> 16) & 0xffu)
+#define RS_SP(r) ((r).sp)
+#define RS_FIFO_N(r) ((r).fw - (r).fr)
 
 static __device__ __forceinline__ void ray_begin(RayState& r, const LdsStack& stk, const DevScene& S, jvec3 o, jvec3 d, int32_t skip) {
   const jvec3 inv = jv(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
@@ -245,7 +247,7 @@ static __device__ __forceinline__ void ray_begin(RayState& r, const LdsStack& st
 #else
   r.skipx = (skip < 0 ? 0x7fffffffu : (uint32_t)skip * 48u) | (exact ? 0x80000000u : 0u);
 #endif
-  r.ctl = 0;
+  r.sp = r.fw = r.fr = 0;
   r.leaf = 0;
   r.cur = S.root_ref;
   lds_putf(stk, LW_INVX, inv.x);
@@ -268,7 +270,7 @@ static __device__ __forceinline__ bool ray_can_test(const RayState& r) { return 
 // the walk's next reference: top of the stack, or JADE_REF_NONE when it is empty
 static __device__ __forceinline__ uint32_t walk_pop(RayState& r, const LdsStack& stk) {
   if (RS_SP(r) == 0) return JADE_REF_NONE;
-  r.ctl -= 1u;
+  r.sp -= 1u;
   return stack_pop(stk, (int)RS_SP(r));
 }
 static __device__ __forceinline__ void leaf_queue(RayState& r, const LdsStack& stk, uint32_t ref) {
@@ -276,9 +278,9 @@ static __device__ __forceinline__ void leaf_queue(RayState& r, const LdsStack& s
   if (r.leaf == 0) {
     r.leaf = ref;
   } else {
-    const uint32_t slot = ((r.ctl >> 8) + (r.ctl >> 16)) & (JADE_LDS_FIFO - 1);
+    const uint32_t slot = r.fw & (JADE_LDS_FIFO - 1);
     lds_put(stk, LW_FIFO + (int)slot, ref);
-    r.ctl += 1u << 16;
+    r.fw += 1u;
   }
 }
 
@@ -329,9 +331,9 @@ static __device__ __forceinline__ void ray_step_tri(RayState& r, const DevScene&
   }
   if ((r.leaf & 15u) == 0) {  // leaf finished: next one from the FIFO
     if (RS_FIFO_N(r)) {
-      const uint32_t head = (r.ctl >> 8) & 0xffu;
+      const uint32_t head = r.fr & (JADE_LDS_FIFO - 1);
       r.leaf = lds_get(stk, LW_FIFO + (int)head);
-      r.ctl = (r.ctl & 0xffff00ffu) - (1u << 16) + (((head + 1u) & (JADE_LDS_FIFO - 1)) << 8);
+      r.fr += 1u;
     } else {
       r.leaf = 0;
     }
@@ -423,7 +425,7 @@ static __device__ __forceinline__ void ray_step_node(RayState& r, const DevScene
         cur = far;
       } else {
         stack_push(stk, (int)RS_SP(r), far);
-        r.ctl += 1u;
+        r.sp += 1u;
         cur = near;
       }
     } else if (in1 || in2) {
@@ -509,18 +511,16 @@ static __device__ __forceinline__ void ray_step_node_s(RayState& r, const DevSce
   const bool push = both && !near_leaf_ok;
   const uint32_t next = both ? (near_leaf_ok ? far : near) : near;
   const bool need_pop = is_leaf || !any || (!both && near_leaf_ok);
-  uint32_t ctl = r.ctl;
   // ---- leaf_queue
   {
     const bool lq = (leafv & 15u) != 0;  // (an empty leaf cannot happen for a valid BVH)
     const bool to_fifo = lq && r.leaf != 0;
-    const uint32_t slot = ((ctl >> 8) + (ctl >> 16)) & (JADE_LDS_FIFO - 1);
-    lds_put_w(stk, to_fifo ? (uint32_t)LW_FIFO + slot : (uint32_t)LW_DUMMY, leafv);
+    lds_put_w(stk, to_fifo ? (uint32_t)LW_FIFO + (r.fw & (JADE_LDS_FIFO - 1)) : (uint32_t)LW_DUMMY, leafv);
     r.leaf = (lq && r.leaf == 0) ? leafv : r.leaf;
-    ctl += to_fifo ? (1u << 16) : 0u;
+    r.fw += to_fifo ? 1u : 0u;
   }
   // ---- push the far child
-  uint32_t sp = ctl & 0xffu;
+  uint32_t sp = r.sp;
   lds_put_w(stk, (push && sp < JADE_LDS_STACK) ? sp : (uint32_t)LW_DUMMY, far);
   if (push && sp >= JADE_LDS_STACK) stk.spill[(size_t)(sp - JADE_LDS_STACK) * stk.stride_spill] = far;  // rare
   sp += push ? 1u : 0u;
@@ -532,7 +532,7 @@ static __device__ __forceinline__ void ray_step_node_s(RayState& r, const DevSce
   if (do_pop && sp1 >= JADE_LDS_STACK) top = stk.spill[(size_t)(sp1 - JADE_LDS_STACK) * stk.stride_spill];  // rare
   sp -= do_pop ? 1u : 0u;
   r.cur = need_pop ? (do_pop ? top : JADE_REF_NONE) : next;
-  r.ctl = (ctl & ~0xffu) | sp;
+  r.sp = sp;
 }
 
 #if !JADE_PAIR
@@ -558,13 +558,10 @@ static __device__ __forceinline__ void ray_step_tri_s(RayState& r, const DevScen
   }
   // leaf finished: the next one from the FIFO, if any
   const bool fin = (leaf & 15u) == 0;
-  const uint32_t ctl = r.ctl;
-  const bool has = ((ctl >> 16) & 0xffu) != 0;
-  const uint32_t head = (ctl >> 8) & 0xffu;
-  const uint32_t nxt = lds_get_w(stk, (uint32_t)LW_FIFO + (head & (JADE_LDS_FIFO - 1)));
-  const uint32_t ctl2 = (ctl & 0xffff00ffu) - (1u << 16) + (((head + 1u) & (JADE_LDS_FIFO - 1)) << 8);
+  const bool has = r.fw != r.fr;
+  const uint32_t nxt = lds_get_w(stk, (uint32_t)LW_FIFO + (r.fr & (JADE_LDS_FIFO - 1)));
   r.leaf = fin ? (has ? nxt : 0u) : leaf;
-  r.ctl = (fin && has) ? ctl2 : ctl;
+  r.fr += (fin && has) ? 1u : 0u;
 }
 
 #endif  // !JADE_PAIR
@@ -662,12 +659,9 @@ static __device__ __forceinline__ void ray_step_tri_s(RayState& r, const DevScen
   }
   // leaf finished: the next one from the FIFO, if any
   const bool fin = (leaf & 15u) == 0;
-  const uint32_t ctl = r.ctl;
-  const bool has = ((ctl >> 16) & 0xffu) != 0;
-  const uint32_t head = (ctl >> 8) & 0xffu;
-  const uint32_t nxt = lds_get_w(stk, (uint32_t)LW_FIFO + (head & (JADE_LDS_FIFO - 1)));
-  const uint32_t ctl2 = (ctl & 0xffff00ffu) - (1u << 16) + (((head + 1u) & (JADE_LDS_FIFO - 1)) << 8);
+  const bool has = r.fw != r.fr;
+  const uint32_t nxt = lds_get_w(stk, (uint32_t)LW_FIFO + (r.fr & (JADE_LDS_FIFO - 1)));
   r.leaf = fin ? (has ? nxt : 0u) : leaf;
-  r.ctl = (fin && has) ? ctl2 : ctl;
+  r.fr += (fin && has) ? 1u : 0u;
 }
 #endif  // JADE_PAIR
