@@ -44,16 +44,18 @@
 #endif
 /* leaf cursors waiting for their triangle tests, same LDS column (power of two) */
 #define JADE_LDS_STATE 9  /* ray-state words, same column (jade_trace.h): 21 words per lane */
-// k_trace runs ONE 1024-thread workgroup per CU (4 waves/SIMD; 5 and 6 waves measured +6 % / +6 % at 256 threads, see
-// DESIGN.md): its lanes' columns take 80 KB of the CU's 160 KB of LDS and the rest holds the top of the BVH
-// (JADE_LDS_TOP_NODES node records, the ones with the largest boxes), staged once per launch.  PMC showed the kernel
-// bound by the vector-memory address/tag path (TA busy 79 %, 25 tag look-ups per wave load: every lane gathers its own
-// 64-B node record), with the LDS idle (7 %): node visits served from LDS never enter that path.
+// k_trace and k_light run 256-thread workgroups, 5 / 4 per CU; each block stages the top of the BVH in LDS once per
+// launch (JADE_LDS_TOP_NODES node records, the ones with the largest boxes: jade_scene_create orders the internal nodes
+// by box area so that any prefix is a connected top).  A visit of such a node is four ds_read_b128 of a plane layout
+// instead of four 16-B gathers through the vector-memory path.  Measured: -3 % of k_trace.  What did NOT
+// pay: one 1024-thread workgroup per CU with 1 272 nodes staged (4 waves/SIMD: +11 % time from the lost occupancy,
+// -3 % from the staging) - the kernel is bound by VALU issue, not by that path (an extra 16-B gather per visit costs
+// +0.5 %), so LDS staging buys little and occupancy matters more.
 #ifndef JADE_TRACE_BLOCK
 #define JADE_TRACE_BLOCK 256
 #endif
-#ifndef JADE_LDS_TOP_NODES  /* 0 = no staging (A/B builds); 6 blocks x (21 KB of columns + 5 KB of nodes) = 156 of the CU's 160 KB */
-#define JADE_LDS_TOP_NODES 80
+#ifndef JADE_LDS_TOP_NODES  /* 0 = no staging (A/B builds); 5 blocks x (21 KB of columns + 10 KB of nodes) = 155 of the CU's 160 KB */
+#define JADE_LDS_TOP_NODES 160 /* k_trace per 1024-spp step of C3: 570 ms without, 552 with 80, 545 with 160 */
 #endif
 #define JADE_RECORD_MEMORY 0.60 /* share of the free device memory that path records + partial sums may take: paths in \
                                   flight are what fills the wide passes (1080p on one GPU: 32 -> 256 records per pixel = +21 %) */
