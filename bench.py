@@ -21,9 +21,10 @@ value = (primary + secondary rays traced by all ranks in the K timed steps) / ma
 roofline: the dominant kernel, k_trace (BVH traversal + triangle tests), against the roof that BINDS it: VALU
         issue.  achieved = VALU lane-operations per second = (lane-ops per ray, SQ_THREAD_CYCLES_VALU from the
         rocprofv3 --pmc pass of this same command, profiles/valu_issue.json) x (rays this run traced) / (k_trace
-        time of this run, HIP events on the kernel's own stream); peak = 1024 SIMDs x 16 lane-ops per clock x 2.4 GHz
-        (one wave64 VALU instruction per SIMD per 4 clocks, see VALU_PEAK_TLANEOPS).  frac is therefore (lanes active
-        per VALU instruction / 64) x (share of quad-cycles in which the SIMD's VALU issues) x (clock held / 2.4 GHz), <= 1.
+        time of this run, HIP events on the kernel's own stream); peak = 1024 SIMDs x 32 lanes per clock x 2.4 GHz
+        (see VALU_PEAK_TLANEOPS).  frac = (lanes active per VALU instruction / 64) x (VALU instructions issued per SIMD
+        per 2 clocks) x (clock held / 2.4 GHz), <= 1.  `binding` names the roof that is nearer for this configuration:
+        VALU issue on C3 (scene L2-resident), HBM on C5 (873k triangles: 49 % L2 hits, 5.4 TB/s of HBM traffic).
 roofline_hbm: the HBM view SURVEY.md 8d prices the path with.  achieved = MEASURED HBM bytes (PMC FETCH_SIZE x 2 +
         WRITE_SIZE per ray, profiles/hbm_traffic.json) x rays / k_trace time, against 8 TB/s; `algorithmic_GBps` is
         the reference traversal's 40 B per node record + 36 B per triangle test delivered per second — it exceeds
@@ -45,12 +46,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s
-# VALU issue roof: one wave64 VALU instruction per SIMD per 4 clocks = 16 lane-ops per clock per SIMD.  That is the unit the SQ
-# itself counts in (SQ_ACTIVE_INST_VALU = 1.007 quad-cycles per VALU instruction in every kernel here) and the rate at which
-# k_trace saturates: its time follows its VALU instruction count (ablations) with 4 x ACTIVE_INST_VALU / SIMD-cycles
-# at 0.99.  MI355X_MICROARCH.md's 2-clock figure holds for independent back-to-back v_fma pairs (SQ_ACTIVE_INST_VALU2: 14 % of
-# this kernel's quad-cycles); against that ideal every fraction below is halved (frac_if_dual_issue).
-VALU_PEAK_TLANEOPS = 1024 * 16 * 2.4e9 / 1e12  # 256 CUs x 4 SIMDs, 2.4 GHz = 39.3 T lane-ops/s
+# VALU issue roof (MI355X_MICROARCH.md: 4 SIMD-32 per CU, a wave64 VALU instruction issues in 2 clocks): 32 lane-operations per
+# clock per SIMD.  That rate needs instructions the sequencer can pair (SQ_ACTIVE_INST_VALU2); a wave's own dependent stream issues
+# one per 4 clocks, which is the unit SQ_ACTIVE_INST_VALU counts in (1.007 quad-cycles per VALU instruction in every kernel
+# here).  k_trace's time follows its VALU instruction count (ablations) and its SIMDs show 4 x ACTIVE_INST_VALU
+# / SIMD-cycles = 1.05 of a possible 2: the roofline below is priced against the full 2-clock rate, `issue_busy_of_2` says how
+# far the issue side is from it.
+VALU_PEAK_TLANEOPS = 1024 * 32 * 2.4e9 / 1e12  # 256 CUs x 4 SIMDs x 32 lanes, 2.4 GHz = 78.6 T lane-ops/s
 
 
 def parse():
@@ -215,13 +217,13 @@ def main():
                 "Mray_per_s_of_this_kernel": rays_rank / trace_s / 1e6 if trace_s > 0 else None}
         if valu and valu.get("valu_lane_ops_per_ray") and trace_s > 0:
             ach = valu["valu_lane_ops_per_ray"] * rays_rank / trace_s / 1e12
-            roof.update({"achieved": ach, "frac": ach / VALU_PEAK_TLANEOPS, "frac_if_dual_issue": ach / (2 * VALU_PEAK_TLANEOPS),
+            roof.update({"achieved": ach, "frac": ach / VALU_PEAK_TLANEOPS, "issue_busy_of_2": valu.get("valu_busy"),
                          "valu_lane_ops_per_ray": valu["valu_lane_ops_per_ray"], "valu_wave_insts_per_ray": valu.get("valu_wave_insts_per_ray"),
                          "lanes_per_valu_inst_of_64": valu.get("lanes_per_valu_inst"), "valu_busy_profiled": valu.get("valu_busy"),
                          "counters_from": valu.get("source"),
                          "note": "lane-ops per ray from the rocprofv3 --pmc SQ pass of this command (tracked summary named in "
-                                 "counters_from); rays and k_trace time are this run's.  frac = (lanes of 64 per VALU instruction) x (share of "
-                                 "quad-cycles the VALU issues) x (clock / 2.4 GHz): the share of the chip's VALU lane-slots doing this kernel's work"})
+                                 "counters_from); rays and k_trace time are this run's.  frac = share of the chip's VALU lane-slots (32 per "
+                                 "SIMD per clock) that carry this kernel's work; issue_busy_of_2 = 4 x SQ_ACTIVE_INST_VALU / SIMD-cycles"})
         roof_hbm = {"bound": "hbm", "kernel": "k_trace", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                     "algorithmic_GBps": alg_bytes / (trace_s + st.light_ms * 1e-3) / 1e9 if trace_s > 0 else None,
                     "algorithmic_bytes_per_launch": alg_bytes / launches,
@@ -277,6 +279,7 @@ def main():
             "nodes_per_ray": float(vals[1].item()) / rays_all, "tris_per_ray": float(vals[2].item()) / rays_all,
             "roofline": roof,
             "roofline_hbm": roof_hbm,
+            "binding": None if roof["frac"] is None or roof_hbm["frac"] is None else ("hbm" if roof_hbm["frac"] > roof["frac"] else "valu"),
         }
         if world == 1 and part_world == 1 and not args.no_extras and args.config in ("C2", "C3", "C4"):
             out["statue_closeup"] = closeup(scene, hip, B, H, _abi, cfg, width, height, args.spp_per_step)

@@ -24,7 +24,7 @@ tag = sys.argv[1]
 O = os.path.join(ROOT, "gpurun_out", tag)
 KERNELS = ("k_trace", "k_light", "k_shade", "k_shade_lean", "k_arm", "k_resolve", "k_init")
 N_CU, N_SIMD = 256, 1024
-VALU_PEAK_LANE_OPS = N_SIMD * 16 * 2.4e9  # one wave64 VALU instruction per SIMD per 4 clocks (bench.py, VALU_PEAK_TLANEOPS)
+VALU_PEAK_LANE_OPS = N_SIMD * 32 * 2.4e9  # one wave64 VALU instruction per SIMD per 2 clocks (bench.py, VALU_PEAK_TLANEOPS)
 
 
 def reduce_dir(d):
@@ -101,7 +101,7 @@ def cut(pre, red, label, command):
                          "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU --kernel-trace --output-format csv -- python3 bench.py " + command,
               "derived": "lanes_per_valu_inst = SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU (of 64); valu_busy = 4 * SQ_ACTIVE_INST_VALU / 1024 SIMDs "
                          "/ (SQ_BUSY_CU_CYCLES / 256 CUs); lane_ops = SQ_THREAD_CYCLES_VALU (one per active lane per VALU instruction); "
-                         "VALU peak = 1024 SIMDs x 16 lane-ops/clock x 2.4 GHz = 39.3 T lane-ops/s (one wave64 instruction per SIMD per 4 clocks)",
+                         "VALU peak = 1024 SIMDs x 32 lanes/clock x 2.4 GHz = 78.6 T lane-ops/s; valu_busy is in 4-clock units (1 quad-cycle per instruction), 2.0 = that peak",
               "rays_of_profiled_run": b.get("rays"), "kernels": {}}
         for k, v in g1["kernels"].items():
             blk = sq_block(v)
