@@ -70,7 +70,14 @@ extern "C" {
  * many of a pixel's samples a backend keeps in flight at once.  The lane
  * count is also the most samples of one pixel that can be in flight at once:
  * 1024 lets a GPU that holds an eighth of a 1080p frame (8-GPU tiling) keep as
- * many paths in flight as one that holds the whole frame. */
+ * many paths in flight as one that holds the whole frame.
+ *
+ * Seed reuse: the seed is 32 bits wide and forced odd, i.e. 2^31 distinct streams.  A 1920x1080 frame at
+ * 4096 spp draws 8.5e9 of them, so every seed serves about four (pixel, sample) pairs: their random numbers
+ * are identical (correlated noise between those samples; they see different camera rays, so their paths
+ * differ from the first hit on).  It is the property of the reference's GLSL generator itself (same seed
+ * expression, fshader_render.fsh:82-85), kept so that results stay comparable with it; a host that needs
+ * more distinct streams varies `frame` between renders. */
 #define JADE_SAMPLE_LANES 1024
 
 /* == Triangle_cu, PathTrace.cu:327-338 (112 bytes). */
