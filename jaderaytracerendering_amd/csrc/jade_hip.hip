@@ -848,10 +848,9 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
 #define JADE_LIGHT_WAVES 4
 #endif
 __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_LIGHT_WAVES) void k_light(DevScene S, PathState P, RenderConst R, const int32_t* tile_ids,
-                                                                            uint32_t target_spp, uint32_t* heavy_out, QueueCtl* qc,
-                                                                            uint32_t* spill, DevCounters* ctr) {
+                                                                            uint32_t target_spp, uint32_t* heavy_regions, uint32_t region_cap,
+                                                                            uint32_t* wave_counts, uint32_t* spill, DevCounters* ctr) {
   __shared__ uint32_t lds_cols[JADE_CTX_WORDS * JADE_TRACE_BLOCK];
-  __shared__ uint32_t sh_def[JADE_TRACE_BLOCK / 64], sh_base;
   __shared__ uint32_t sh_ctr[JADE_TRACE_BLOCK / 64][8];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   LdsStack stk;
@@ -878,8 +877,13 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_LIGHT_WAVES) void k_light(De
   c.c_primary = c.c_shadow = c.c_shaded = c.c_samples = c.c_cls = 0;
   // records are dealt to the resident blocks in chunks of one block (a persistent grid: the LDS copy of the tree top is
   // made once per block, not once per 256 records)
-  for (size_t base = (size_t)blockIdx.x * JADE_TRACE_BLOCK; base < (size_t)npix; base += (size_t)gridDim.x * JADE_TRACE_BLOCK) {
-    const size_t p64 = base + threadIdx.x;
+  // (per WAVE: a wave that is through its 64 records takes its next 64 at once - no barrier, no shared counter; the
+  // records it hands to k_shade go into a region of the list that is this wave's own, compacted by k_heavy_pack)
+  const uint32_t wave_id = blockIdx.x * (JADE_TRACE_BLOCK / 64) + (uint32_t)w;
+  uint32_t* const my_region = heavy_regions + (size_t)wave_id * region_cap;
+  uint32_t n_deferred = 0;
+  for (size_t base = (size_t)wave_id * 64; base < (size_t)npix; base += (size_t)gridDim.x * JADE_TRACE_BLOCK) {
+    const size_t p64 = base + (size_t)lane;
     const bool have = p64 < (size_t)npix;
     const int p = have ? (int)p64 : 0;
     const uint32_t word = P.stage[p];
@@ -1064,26 +1068,14 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_LIGHT_WAVES) void k_light(De
         P.stage[p] = ST_IDLE;
       }
     }
-    // ---- hand-over list: wave scan, one atomic per block
+    // ---- hand-over: append to this wave's region
     {
       const unsigned long long dm = __ballot(defer);
-      const uint32_t doff = (uint32_t)__popcll(dm & ((1ull << lane) - 1ull));
-      if (lane == 0) sh_def[w] = (uint32_t)__popcll(dm);
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        uint32_t td = 0;
-        for (int i = 0; i < JADE_TRACE_BLOCK / 64; ++i) td += sh_def[i];
-        sh_base = td ? atomicAdd(&qc->heavy, td) : 0u;
-      }
-      __syncthreads();
-      if (defer) {
-        uint32_t wd = sh_base + doff;
-        for (int i = 0; i < w; ++i) wd += sh_def[i];
-        heavy_out[wd] = (uint32_t)p;
-      }
-      __syncthreads();  // sh_def / sh_base are reused by the next chunk
+      if (defer) my_region[n_deferred + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull))] = (uint32_t)p;
+      n_deferred += (uint32_t)__popcll(dm);
     }
   }
+  if (lane == 0) wave_counts[wave_id] = n_deferred;
   // ---- work counters: per wave into LDS, then one set of atomics per block (as shade_tail), and V / T as k_trace
   {
     const uint32_t s0 = (uint32_t)wave_sum_u32(c.c_primary), s2 = (uint32_t)wave_sum_u32(c.c_shaded), s3 = (uint32_t)wave_sum_u32(c.c_samples);
@@ -1112,6 +1104,40 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_LIGHT_WAVES) void k_light(De
       if (t) atomicAdd(reinterpret_cast<unsigned long long*>(cs) + wordi, t);
     }
   }
+}
+
+// Hand-over list of k_light: every wave filled a region of its own; one block turns the per-wave counts into offsets
+// (and the total into qc->heavy, where k_shade reads it), then each region is copied to its place in the dense list.
+__global__ __launch_bounds__(1024) void k_heavy_scan(uint32_t* wave_counts, uint32_t n_waves, QueueCtl* qc) {
+  __shared__ uint32_t sh[1024];
+  __shared__ uint32_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < n_waves; base += 1024) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < n_waves ? wave_counts[i] : 0u;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+      const uint32_t t = threadIdx.x >= off ? sh[threadIdx.x - off] : 0u;
+      __syncthreads();
+      sh[threadIdx.x] += t;
+      __syncthreads();
+    }
+    const uint32_t incl = sh[threadIdx.x], c0 = carry;
+    if (i < n_waves) wave_counts[n_waves + i] = c0 + incl - v;  // exclusive offsets live behind the counts
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = c0 + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) qc->heavy = carry;
+}
+
+__global__ void k_heavy_pack(const uint32_t* heavy_regions, uint32_t region_cap, const uint32_t* wave_counts, uint32_t n_waves, uint32_t* dense) {
+  const uint32_t wv = blockIdx.x;
+  const uint32_t n = wave_counts[wv], off = wave_counts[n_waves + wv];
+  const uint32_t* src = heavy_regions + (size_t)wv * region_cap;
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dense[off + i] = src[i];
 }
 
 // ACESToneMapping + gamma + BGR pack, PathTrace.cu:680-682, 1457-1473.
@@ -1213,7 +1239,7 @@ struct jade_scene {
   jade_render_params rp{};
   RenderConst rc{};
   PathState ps{};
-  DevBuf b_state, b_tiles, b_queue, b_active[2], b_ctl, b_ctr, b_spill, b_out_rgb, b_out_bgr;
+  DevBuf b_state, b_tiles, b_queue, b_active[2], b_ctl, b_ctr, b_spill, b_out_rgb, b_out_bgr, b_wavecnt;
   std::vector<int32_t> tile_ids;
   int trace_blocks = 0;
   int light_blocks = 0;       // persistent grid of k_light
@@ -1611,8 +1637,10 @@ static int setup_state(jade_scene* s, int npx, int rpp, int nslots) {
   P.skip = (int32_t*)(b + o_skip); P.aux = (float*)(b + o_aux); P.auxi = (int32_t*)(b + o_auxi);
   P.dir = (float*)(b + o_dir); P.hit = (int32_t*)(b + o_hit); P.hpt = (float*)(b + o_hpt);
   HIP_TRY(s->b_queue.alloc(K * N * 4));
-  HIP_TRY(s->b_active[0].alloc(N * 4));
+  // b_active[0] doubles as k_light's per-wave hand-over regions: up to 64 records of slack per wave of its grid
+  HIP_TRY(s->b_active[0].alloc((N + (size_t)s->light_blocks * JADE_TRACE_BLOCK + 64) * 4));
   HIP_TRY(s->b_active[1].alloc(N * 4));
+  HIP_TRY(s->b_wavecnt.alloc((size_t)2 * s->light_blocks * (JADE_TRACE_BLOCK / 64) * 4));
   if (!s->b_spill.p)
     HIP_TRY(s->b_spill.alloc((size_t)JADE_TRACE_CTXS * (JADE_BVH_STACK_CAPACITY - JADE_LDS_STACK) * s->trace_blocks * JADE_TRACE_BLOCK * 4));
   return JADE_OK;
@@ -1772,9 +1800,20 @@ static int run_passes(jade_scene* s, uint32_t target_spp, bool may_carry, double
         if (!e) HIP_TRY(hipEventCreate(&e));
       HIP_TRY(hipEventRecord(s->ev_light[0], s->stream));
       light_timed = true;
-      hipLaunchKernelGGL(k_light, dim3((unsigned)std::min<size_t>((size_t)s->light_blocks, ((size_t)npix + JADE_TRACE_BLOCK - 1) / JADE_TRACE_BLOCK)),
-                         dim3(JADE_TRACE_BLOCK), 0, s->stream, s->dev, s->ps, s->rc, s->b_tiles.as<int32_t>(), target_spp,
-                         s->b_active[1].as<uint32_t>(), qc, s->b_spill.as<uint32_t>(), s->b_ctr.as<DevCounters>());
+      {
+        const unsigned lb = (unsigned)std::min<size_t>((size_t)s->light_blocks, ((size_t)npix + JADE_TRACE_BLOCK - 1) / JADE_TRACE_BLOCK);
+        const uint32_t n_waves = lb * (JADE_TRACE_BLOCK / 64);
+        // a wave takes every n_waves-th chunk of 64 records: its region must hold all of them
+        const uint32_t region_cap = (uint32_t)((((size_t)npix + 63) / 64 + n_waves - 1) / n_waves) * 64u;
+        if ((size_t)region_cap * n_waves > s->b_active[0].bytes / 4 || (size_t)2 * n_waves * 4 > s->b_wavecnt.bytes)
+          return fail(JADE_ERR_DEVICE, "hand-over regions do not fit (internal sizing error)");
+        hipLaunchKernelGGL(k_light, dim3(lb), dim3(JADE_TRACE_BLOCK), 0, s->stream, s->dev, s->ps, s->rc, s->b_tiles.as<int32_t>(), target_spp,
+                           s->b_active[0].as<uint32_t>(), region_cap, s->b_wavecnt.as<uint32_t>(), s->b_spill.as<uint32_t>(),
+                           s->b_ctr.as<DevCounters>());
+        hipLaunchKernelGGL(k_heavy_scan, dim3(1), dim3(1024), 0, s->stream, s->b_wavecnt.as<uint32_t>(), n_waves, qc);
+        hipLaunchKernelGGL(k_heavy_pack, dim3(n_waves), dim3(256), 0, s->stream, s->b_active[0].as<uint32_t>(), region_cap,
+                           s->b_wavecnt.as<uint32_t>(), n_waves, s->b_active[1].as<uint32_t>());
+      }
       HIP_TRY(hipEventRecord(s->ev_light[1], s->stream));
       if (log_passes) HIP_TRY(hipEventRecord(sm, s->stream));
       hipLaunchKernelGGL(k_shade, dim3(nb), dim3(JADE_SHADE_BLOCK), 0, s->stream, s->dev, s->ps, s->rc, s->b_tiles.as<int32_t>(),
