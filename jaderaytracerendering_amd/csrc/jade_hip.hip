@@ -465,6 +465,7 @@ __global__ __launch_bounds__(JADE_LEAN_BLOCK) void k_shade_lean(DevScene S, Path
   shade_tail<true, JADE_LEAN_BLOCK / 64>(P, p, st, c, defer, nullptr, heavy_out, queue, qc, ctr);
 }
 
+#define JADE_CTL_RING 16 /* QueueCtl records: entry 0 for passes the host follows one by one, all of them for a batch of passes */
 #ifndef JADE_DUAL
 #define JADE_DUAL 0 /* two rays per lane: a lane whose ray has no work of the picked kind works on its other ray */
 #endif
@@ -523,6 +524,12 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
   }
 #endif
   const uint32_t n = qc->count;
+  if (chunk == 0) {  // batched passes: the host has not seen the queue length (trace_chunk's rule, on the device)
+    const uint32_t waves = gridDim.x * (JADE_TRACE_BLOCK / 64);
+    uint32_t per = n / (waves * 64u * 8u);
+    per = per < 1u ? 1u : (per > JADE_TRACE_CHUNK / 64 ? JADE_TRACE_CHUNK / 64 : per);
+    chunk = per * 64u;
+  }
   const int npix = P.npix;
   const size_t plane = (size_t)P.nslots * npix;
   uint32_t V = 0, T = 0;  // wave totals (uniform: they live in SGPRs)
@@ -1250,9 +1257,12 @@ struct jade_scene {
   uint64_t host_syncs = 0;    // host waits inside step/flush since the last advance() reported them
   double light_ms = 0;        // k_light device time since then
   hipEvent_t ev_light[2] = {};
+  hipEvent_t ev_batch[2 * JADE_CTL_RING] = {};  // k_trace timing of a batch of passes
   ~jade_scene() {
     if (ev_resolve) (void)hipEventDestroy(ev_resolve);
     for (hipEvent_t e : ev_light)
+      if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ev_batch)
       if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev)
       if (e) (void)hipEventDestroy(e);
@@ -1543,7 +1553,7 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
   if (e == hipSuccess) e = upload(s->b_prefix, d->prefix_area, (size_t)d->n_triangles, s->stream);
   if (e == hipSuccess) e = upload(s->b_segs, d->obj_segs, (size_t)d->n_objects, s->stream);
   if (e == hipSuccess) e = upload(s->b_env, d->env_rgb, (size_t)3 * d->env_width * d->env_height, s->stream);
-  if (e == hipSuccess) e = s->b_ctl.alloc(sizeof(QueueCtl));
+  if (e == hipSuccess) e = s->b_ctl.alloc(sizeof(QueueCtl) * JADE_CTL_RING);
   if (e == hipSuccess) e = s->b_ctr.alloc(sizeof(DevCounters) * JADE_CTR_SHARDS);
   if (e != hipSuccess) {
     delete s;
@@ -1747,9 +1757,8 @@ static hipError_t sum_counters(jade_scene* s, DevCounters* out) {
   return e;
 }
 
-// shade/trace passes until a shade pass emits no ray.  The host reads the
-// queue length after every shade pass (that sync is also what lets one event
-// pair time every k_trace launch on this stream).
+// shade/trace passes until a shade pass emits no ray (or the step may carry the rest over).  The host follows the first
+// passes of a step one by one (it picks the schedule from the counts) and the list-mode passes in batches of 8-16.
 static int run_passes(jade_scene* s, uint32_t target_spp, bool may_carry, double* ms_out, double* trace_ms_out, uint64_t* launches_out) {
   const int npix = s->ps.npix;
   QueueCtl* qc = s->b_ctl.as<QueueCtl>();
@@ -1782,8 +1791,67 @@ static int run_passes(jade_scene* s, uint32_t target_spp, bool may_carry, double
   bool have_list = true;  // b_active[cur] lists the active records
   bool light_timed = false;
   float shade_ms = 0, lean_ms = 0;
+  static const double carry_frac = getenv("JADE_CARRY_FRACTION") ? atof(getenv("JADE_CARRY_FRACTION")) : JADE_CARRY_FRACTION;
+  auto carry_now = [&](uint32_t act) {
+    return may_carry && ((act < JADE_CARRY_RECORDS && (uint64_t)act * 1024 < (uint64_t)n_armed) ||
+                         (carry_frac > 0 && (double)act < carry_frac * (double)n_armed));
+  };
+  // JADE_BATCH=0: the host follows every pass (the schedule before batching existed)
+  static const bool batching = !(getenv("JADE_BATCH") && atoi(getenv("JADE_BATCH")) == 0);
   while (n_active) {
     const bool lean_mode = split_ok && (uint64_t)n_active * 4 >= (uint64_t)npix;
+    if (!lean_mode && have_list && batching && !log_passes && pass_no > 0) {
+      // ---- a BATCH of list-mode passes without the host in between: pass j's k_shade takes its length from the record
+      // count pass j-1 left on the device (QueueCtl ring), k_trace sizes its chunks itself; a pass that finds nothing
+      // to do is three empty launches.  The host looks once per batch: where the paths ended, whether to carry.
+      const int B = n_active > (1u << 20) ? 8 : JADE_CTL_RING;  // (long passes: a shorter batch, so that the carry point is not overshot by much)
+      const unsigned nbb = (n_active + JADE_SHADE_BLOCK - 1) / JADE_SHADE_BLOCK;  // the active count only shrinks: an upper bound for all
+      for (hipEvent_t& e : s->ev_batch)
+        if (!e) HIP_TRY(hipEventCreate(&e));
+      HIP_TRY(hipMemsetAsync(qc, 0, sizeof(QueueCtl) * B, s->stream));
+      for (int j = 0; j < B; ++j) {
+        hipLaunchKernelGGL(k_shade, dim3(nbb), dim3(JADE_SHADE_BLOCK), 0, s->stream, s->dev, s->ps, s->rc, s->b_tiles.as<int32_t>(),
+                           target_spp, s->b_active[cur].as<uint32_t>(), n_active, j ? &qc[j - 1].active : (const uint32_t*)nullptr,
+                           s->b_active[cur ^ 1].as<uint32_t>(), s->b_queue.as<uint32_t>(), qc + j, s->b_ctr.as<DevCounters>());
+        cur ^= 1;
+        HIP_TRY(hipEventRecord(s->ev_batch[2 * j], s->stream));
+        hipLaunchKernelGGL(k_trace, dim3((unsigned)s->trace_blocks), dim3(JADE_TRACE_BLOCK), 0, s->stream, s->dev, s->ps,
+                           s->b_queue.as<uint32_t>(), qc + j, s->b_spill.as<uint32_t>(), s->b_ctr.as<DevCounters>(), 0u);
+        HIP_TRY(hipEventRecord(s->ev_batch[2 * j + 1], s->stream));
+      }
+      HIP_TRY(hipGetLastError());
+      QueueCtl host_ring[JADE_CTL_RING];
+      HIP_TRY(hipMemcpyAsync(host_ring, qc, sizeof(QueueCtl) * B, hipMemcpyDeviceToHost, s->stream));
+      HIP_TRY(hipStreamSynchronize(s->stream));
+      s->host_syncs += 1;
+      if (trace_pending) {  // the k_trace launch of the pass before the batch
+        float t = 0;
+        HIP_TRY(hipEventElapsedTime(&t, ta, tb));
+        trace_ms += t;
+        launches += 1;
+        trace_pending = false;
+      }
+      bool ended = false;
+      for (int j = 0; j < B; ++j) {
+        if (host_ring[j].count == 0) {  // this pass emitted nothing: every path has ended (later passes of the batch were empty)
+          n_active = 0;
+          ended = true;
+          break;
+        }
+        float t = 0;
+        HIP_TRY(hipEventElapsedTime(&t, s->ev_batch[2 * j], s->ev_batch[2 * j + 1]));
+        trace_ms += t;
+        launches += 1;
+        n_active = host_ring[j].active;
+        ++pass_no;
+      }
+      if (ended) break;
+      if (carry_now(n_active)) {
+        s->tail_pending = true;
+        break;
+      }
+      continue;
+    }
     if (!lean_mode && !have_list) {
       cur = 0;
       HIP_TRY(hipMemsetAsync(qc, 0, 16, s->stream));
@@ -1869,9 +1937,7 @@ static int run_passes(jade_scene* s, uint32_t target_spp, bool may_carry, double
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(tb, s->stream));
     trace_pending = true;
-    static const double carry_frac = getenv("JADE_CARRY_FRACTION") ? atof(getenv("JADE_CARRY_FRACTION")) : JADE_CARRY_FRACTION;
-    if (may_carry && ((n_active < JADE_CARRY_RECORDS && (uint64_t)n_active * 1024 < (uint64_t)n_armed) ||
-                      (carry_frac > 0 && (double)n_active < carry_frac * (double)n_armed))) {
+    if (carry_now(n_active)) {
       // The few long paths left would take dozens of nearly empty passes: leave them suspended (their
       // rays are traced, their hits wait to be folded in) for the next step's first pass, or for flush.
       s->tail_pending = true;

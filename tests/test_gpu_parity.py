@@ -206,9 +206,10 @@ def test_result_independent_of_shade_schedule(hip, monkeypatch):
         p = B.params_from_config(cfg, spp=spp)
         p.width, p.height = 40, 36
         ref = None
-        for split, fused in (("1", "1"), ("1", "0"), ("0", "1")):
+        for split, fused, batch in (("1", "1", "1"), ("1", "0", "1"), ("0", "1", "1"), ("1", "1", "0")):
             monkeypatch.setenv("JADE_SHADE_SPLIT", split)
             monkeypatch.setenv("JADE_FUSED", fused)   # the step's first pass as the fused k_light, or as k_shade_lean + k_trace
+            monkeypatch.setenv("JADE_BATCH", batch)   # list-mode passes in batches (device-side counts), or one host sync per pass
             with hip.scene(hs) as sc:
                 rgb, bgr, st = sc.render(p)
             if ref is None:
