@@ -1797,7 +1797,7 @@ static int run_passes(jade_scene* s, uint32_t target_spp, bool may_carry, double
                          (carry_frac > 0 && (double)act < carry_frac * (double)n_armed));
   };
   // JADE_BATCH=0: the host follows every pass (the schedule before batching existed)
-  static const bool batching = !(getenv("JADE_BATCH") && atoi(getenv("JADE_BATCH")) == 0);
+  const bool batching = !(getenv("JADE_BATCH") && atoi(getenv("JADE_BATCH")) == 0);
   while (n_active) {
     const bool lean_mode = split_ok && (uint64_t)n_active * 4 >= (uint64_t)npix;
     if (!lean_mode && have_list && batching && !log_passes && pass_no > 0) {
