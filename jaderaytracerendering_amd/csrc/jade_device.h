@@ -62,7 +62,7 @@
 
 struct DevScene {
   const float4* nodes;        // 4 x float4 per internal node
-  const float4* tverts;       // 3 x float4 per triangle (BVH order)
+  const float4* tverts;       // 5 x float4 per pair of triangles of a leaf (jade_trace.h)
   const jade_triangle* tris;  // shading records (BVH order)
   const int32_t* emit;
   const int32_t* mapping;
@@ -73,6 +73,7 @@ struct DevScene {
   int32_t n_tris, n_emit;
   uint32_t root_ref;
   uint32_t top_k;             // internal nodes [0, top_k) are the ones k_trace stages in LDS (largest boxes first)
+  uint32_t general_walk;      // an internal node lacks a child (the reference's "child 0"): every wave takes the general node step (jade_trace.h)
 };
 
 // Path records, structure of arrays.  Samples are independent work items
@@ -164,7 +165,7 @@ struct DevCounters {  // two 64-B lines per shard; shade_tail adds by word index
 #define JADE_TRACE_CHUNK 512 /* most rays a wave claims per queue atomic */
 #endif
 #ifndef JADE_REFILL_MIN
-#define JADE_REFILL_MIN 32 /* idle lanes in a wave that trigger write-back + refill (8: 343, 16: 331, 32: 313, 48: 316 ms of k_trace per 256-spp step) */
+#define JADE_REFILL_MIN 16 /* idle lanes in a wave that trigger k_trace's write-back + refill.  Round 1, all rays: 8: 343, 16: 331, 32: 313, 48: 316 ms of k_trace per 256-spp step; round 2, heavy rays only: 8: 140, 12: 139, 16: 138, 24: 137-139, 32: 139-142, 40: 147 */
 #endif
 
 // The per-(pixel, lane) partial sums: 3 planes of JADE_SAMPLE_LANES * npx floats — a full 4K frame on

@@ -466,17 +466,7 @@ __global__ __launch_bounds__(JADE_LEAN_BLOCK) void k_shade_lean(DevScene S, Path
 }
 
 #define JADE_CTL_RING 16 /* QueueCtl records: entry 0 for passes the host follows one by one, all of them for a batch of passes */
-#ifndef JADE_DUAL
-#define JADE_DUAL 0 /* two rays per lane: a lane whose ray has no work of the picked kind works on its other ray */
-#endif
-#define JADE_CTX_WORDS (JADE_LDS_STACK + JADE_LDS_FIFO + JADE_LDS_STATE) /* LDS words per lane and ray context */
-#define JADE_TRACE_CTXS (JADE_DUAL ? 2 : 1)
-#ifndef JADE_STRAIGHT
-#define JADE_STRAIGHT 1 /* branch-free node / triangle steps (jade_trace.h) */
-#endif
-#if JADE_PAIR && !JADE_STRAIGHT
-#error "JADE_PAIR (pair vertex records) needs the straight-line steps: build with -DJADE_PAIR=0 -DJADE_STRAIGHT=0 for the branchy form"
-#endif
+#define JADE_CTX_WORDS (JADE_LDS_STACK + JADE_LDS_FIFO + JADE_LDS_STATE) /* LDS words per lane */
 #ifndef JADE_TRACE_NT
 #define JADE_TRACE_NT 1 /* k_trace reads and writes the ray records with non-temporal hints */
 #endif
@@ -504,11 +494,12 @@ __global__ __launch_bounds__(JADE_LEAN_BLOCK) void k_shade_lean(DevScene S, Path
 #endif
 __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(DevScene S, PathState P, const uint32_t* queue, QueueCtl* qc,
                                                            uint32_t* spill, DevCounters* ctr, uint32_t chunk) {
-  __shared__ uint32_t lds_cols[JADE_TRACE_CTXS * JADE_CTX_WORDS * JADE_TRACE_BLOCK];
+  __shared__ __attribute__((aligned(JADE_COLS_ALIGN))) uint32_t lds_cols[JADE_CTX_WORDS * JADE_TRACE_BLOCK];
   const int lane = threadIdx.x & 63;
   const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
   LdsStack stk;
   stk.lds = lds_cols + threadIdx.x;
+  stk.col = lds_addr_of(stk.lds);
   stk.spill = spill + gtid;
   stk.stride_spill = gridDim.x * blockDim.x;
   stk.top = nullptr;
@@ -517,7 +508,7 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
   __shared__ float4 lds_top[4 * JADE_LDS_TOP_NODES];
   {  // stage the top of the tree: record i's j-th 16 bytes -> plane j, entry i (coalesced reads of S.nodes)
     const uint32_t k = S.top_k;  // <= JADE_LDS_TOP_NODES (jade_scene_create)
-    for (uint32_t i = threadIdx.x; i < 4u * k; i += JADE_TRACE_BLOCK) lds_top[(i & 3u) * k + (i >> 2)] = S.nodes[i];
+    for (uint32_t i = threadIdx.x; i < 4u * k; i += JADE_TRACE_BLOCK) lds_top[(i & 3u) * JADE_LDS_TOP_NODES + (i >> 2)] = S.nodes[i];
     __syncthreads();
     stk.top = lds_top;
     stk.top_k = k;
@@ -533,169 +524,10 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
   const int npix = P.npix;
   const size_t plane = (size_t)P.nslots * npix;
   uint32_t V = 0, T = 0;  // wave totals (uniform: they live in SGPRs)
-#if JADE_STRAIGHT
   uint32_t vcnt = 0, tcnt = 0;  // per lane, summed over the wave once at the end (a ballot + popcount per unit was 8 instructions)
-#endif
 #if JADE_TRACE_PROFILE
   uint32_t prof_units = 0, prof_lanes = 0;  // development: units run of one kind (1 node, 2 triangle, 3 any) and lanes that took part
 #endif
-#if JADE_DUAL
-  {
-    // ---- two ray contexts per lane.  The walk and the tests of ONE ray take turns (a wave iteration runs one kind of work),
-    // so in any iteration a third of the lanes that hold a ray have nothing of the picked kind (39 of 64 lanes worked per
-    // unit, PMC).  With two rays per lane, a lane takes part whenever EITHER ray has work of that kind: the working copy
-    // (registers) is filled from the chosen context before the units of a pick and written back after them.
-    static_assert(JADE_STRAIGHT, "the dual-context loop uses the straight-line steps");
-    struct Ctx {
-      RayState r;
-      uint32_t e;   // queue entry: slot * npix + record
-      bool active;  // holds a ray in flight
-      bool wb;      // its ray has finished and the result is still in the LDS column
-    };
-    Ctx A, B;
-    A.active = B.active = A.wb = B.wb = false;
-    A.e = B.e = 0;
-    A.r = RayState{};
-    B.r = RayState{};
-    LdsStack stkA = stk, stkB = stk;
-    stkB.lds = stk.lds + JADE_CTX_WORDS * JADE_TRACE_BLOCK;
-    stkB.spill = stk.spill + (size_t)(JADE_BVH_STACK_CAPACITY - JADE_LDS_STACK) * stk.stride_spill;
-    uint32_t lbase = 0, lend = 0;
-    bool queue_empty = false;
-    // write back the finished rays of one context and refill its idle lanes, once >= JADE_REFILL_MIN of them are idle
-    auto refill = [&](Ctx& c, const LdsStack& ck) {
-      const unsigned long long idle = __ballot(!c.active);
-      const int n_idle = __popcll(idle);
-      if (n_idle < JADE_REFILL_MIN) return;
-      if (c.wb) {
-        const int32_t best = ray_best_index(ck);
-        NT_ST(&P.hit[c.e], best);
-        if (P.hdist) P.hdist[c.e] = lds_getf(ck, LW_BEST_DIST);
-        if (best >= 0) {
-          const jvec3 hp = ray_hit_point(ck);
-          float* hb = P.hpt + c.e;
-          NT_ST(&hb[0], hp.x);
-          NT_ST(&hb[plane], hp.y);
-          NT_ST(&hb[2 * plane], hp.z);
-        }
-        c.wb = false;
-      }
-      if (queue_empty) return;
-      if (lbase >= lend) {
-        uint32_t nb = 0;
-        if (lane == 0) nb = atomicAdd(&qc->next, chunk);
-        nb = __shfl(nb, 0, 64);
-        if (nb >= n) {
-          queue_empty = true;
-          lbase = lend = n;
-        } else {
-          lbase = nb;
-          lend = nb + chunk < n ? nb + chunk : n;
-        }
-      }
-      const uint32_t avail = lend - lbase;
-      const uint32_t take = (uint32_t)n_idle < avail ? (uint32_t)n_idle : avail;
-      const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-      if (!c.active && rank < take) {
-        c.e = NT_LD(&queue[lbase + rank]);
-        const uint32_t k = c.e / (uint32_t)npix, p = c.e - k * (uint32_t)npix;
-        const int32_t skip = NT_LD(&P.skip[p]);
-        const jvec3 o = skip == JADE_SKIP_CAMERA ? jv(P.eye[0], P.eye[1], P.eye[2])
-                                                 : jv(NT_LD(&P.org[p]), NT_LD(&P.org[npix + p]), NT_LD(&P.org[2 * npix + p]));
-        const float* db = P.dir + c.e;
-        const jvec3 d = jv(NT_LD(&db[0]), NT_LD(&db[plane]), NT_LD(&db[2 * plane]));
-        ray_begin(c.r, ck, S, o, d, skip);
-        c.active = true;
-      }
-      V += take;  // the root record of every ray started
-      lbase += take;
-    };
-    for (;;) {
-      refill(A, stkA);
-      refill(B, stkB);
-      if (queue_empty && __ballot(A.active || B.active) == 0ull) {
-        // results still parked in a column (fewer than JADE_REFILL_MIN lanes were idle when the ray ended) are written now
-        if (__ballot(A.wb || B.wb) == 0ull) break;
-        const bool sa = A.active, sb = B.active;  // (both false here)
-        (void)sa; (void)sb;
-        // force the write-back: every lane is idle, so n_idle = 64 >= JADE_REFILL_MIN
-        refill(A, stkA);
-        refill(B, stkB);
-        break;
-      }
-      const bool cwA = A.active && ray_can_walk(A.r), cwB = B.active && ray_can_walk(B.r);
-      const bool ctA = A.active && ray_can_test(A.r), ctB = B.active && ray_can_test(B.r);
-      const int nw = __popcll(__ballot(cwA || cwB)), nt = __popcll(__ballot(ctA || ctB));
-      const bool node_kind = JADE_COST_TRI * nw >= JADE_COST_NODE * nt;
-      // which context works: the one that has this kind of work; if both do, the one with nothing of the OTHER kind
-      // (it would sit out the other kind's picks anyway), else A
-      const bool selB = node_kind ? (cwB && (!cwA || (ctA && !ctB))) : (ctB && (!ctA || (cwA && !cwB)));
-      const bool go0 = node_kind ? (cwA || cwB) : (ctA || ctB);
-      RayState w;
-      w.od.a = selB ? B.r.od.a : A.r.od.a;
-      w.od.b = selB ? B.r.od.b : A.r.od.b;
-      w.od.c = selB ? B.r.od.c : A.r.od.c;
-      w.skipx = selB ? B.r.skipx : A.r.skipx;
-      w.cur = selB ? B.r.cur : A.r.cur;
-      w.leaf = selB ? B.r.leaf : A.r.leaf;
-      w.sp = selB ? B.r.sp : A.r.sp;
-      w.fw = selB ? B.r.fw : A.r.fw;
-      w.fr = selB ? B.r.fr : A.r.fr;
-      LdsStack wk = stkA;
-      wk.lds = selB ? stkB.lds : stkA.lds;
-      wk.spill = selB ? stkB.spill : stkA.spill;
-      if (node_kind) {
-        if (__ballot(go0 && (int32_t)w.skipx < 0) != 0ull) {
-#pragma nounroll
-          for (int rep = 0; rep < JADE_STEPS_PER_PICK; ++rep)
-            if (go0 && ray_can_walk(w)) ray_step_node_s<true>(w, S, wk, vcnt);
-        } else {
-#pragma nounroll
-          for (int rep = 0; rep < JADE_STEPS_PER_PICK; ++rep) {
-#if JADE_TRACE_PROFILE == 1
-            prof_units += 1;
-            prof_lanes += (uint32_t)__popcll(__ballot(go0 && ray_can_walk(w)));
-#endif
-            if (go0 && ray_can_walk(w)) ray_step_node_s<false>(w, S, wk, vcnt);
-          }
-        }
-      } else {
-#pragma nounroll
-        for (int rep = 0; rep < JADE_STEPS_PER_PICK; ++rep) {
-#if JADE_TRACE_PROFILE == 2
-          prof_units += 1;
-          prof_lanes += (uint32_t)__popcll(__ballot(go0 && ray_can_test(w)));
-#endif
-          if (go0 && ray_can_test(w)) ray_step_tri_s(w, S, wk, tcnt);
-        }
-      }
-      // write the working copy back (the origin / direction / skip of a ray never change)
-      if (go0) {
-        if (selB) {
-          B.r.cur = w.cur;
-          B.r.leaf = w.leaf;
-          B.r.sp = w.sp;
-          B.r.fw = w.fw;
-          B.r.fr = w.fr;
-        } else {
-          A.r.cur = w.cur;
-          A.r.leaf = w.leaf;
-          A.r.sp = w.sp;
-          A.r.fw = w.fw;
-          A.r.fr = w.fr;
-        }
-      }
-      if (A.active && ray_done(A.r)) {
-        A.active = false;
-        A.wb = true;
-      }
-      if (B.active && ray_done(B.r)) {
-        B.active = false;
-        B.wb = true;
-      }
-    }
-  }
-#else
   // wave-local chunk of the queue: [lbase, lend) (wave-uniform)
   uint32_t lbase = 0, lend = 0;
   bool queue_empty = false;
@@ -764,10 +596,9 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
       const bool cw = active && ray_can_walk(r), ct = active && ray_can_test(r);
       const int nw = __popcll(__ballot(cw)), nt = __popcll(__ballot(ct));
       if (JADE_COST_TRI * nw >= JADE_COST_NODE * nt) {
-#if JADE_STRAIGHT
-        // the NaN-faithful slab reduction is needed by a ray with a non-finite 1/d or origin only: decided per WAVE (a
-        // scalar branch), not per lane - such rays are rare, and the faithful form is right for every ray
-        if (__ballot(active && (int32_t)r.skipx < 0) != 0ull) {
+        // the general form of the node step (NaN-faithful slabs, missing children) is needed by few waves: decided per WAVE
+        // (a scalar branch), not per lane - it is right for every ray
+        if (S.general_walk || __ballot(active && (int32_t)r.skipx < 0) != 0ull) {
 #pragma nounroll
           for (int rep = 0; rep < JADE_STEPS_PER_PICK; ++rep)
             if (active && ray_can_walk(r)) ray_step_node_s<true>(r, S, stk, vcnt);
@@ -781,19 +612,6 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
             if (active && ray_can_walk(r)) ray_step_node_s<false>(r, S, stk, vcnt);
           }
         }
-#else
-#pragma nounroll
-        for (int rep = 0; rep < JADE_STEPS_PER_PICK; ++rep) {
-          bool c1 = false, c2 = false;
-          const bool go = active && ray_can_walk(r);
-#if JADE_TRACE_PROFILE == 1
-          prof_units += 1;
-          prof_lanes += (uint32_t)__popcll(__ballot(go));
-#endif
-          if (go) ray_step_node(r, S, stk, &c1, &c2);
-          V += (uint32_t)__popcll(__ballot(c1)) + (uint32_t)__popcll(__ballot(c2));
-        }
-#endif
       } else {
 #pragma nounroll
         for (int rep = 0; rep < JADE_STEPS_PER_PICK; ++rep) {
@@ -802,13 +620,7 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
           prof_units += 1;
           prof_lanes += (uint32_t)__popcll(__ballot(go));
 #endif
-#if JADE_STRAIGHT
           if (go) ray_step_tri_s(r, S, stk, tcnt);
-#else
-          bool tested = false;
-          if (go) ray_step_tri(r, S, stk, &tested);
-          T += (uint32_t)__popcll(__ballot(tested));
-#endif
         }
       }
 #if JADE_TRACE_PROFILE == 3
@@ -822,11 +634,8 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
       wb = true;
     }
   }
-#endif  // JADE_DUAL
-#if JADE_STRAIGHT
   V += (uint32_t)wave_sum_u32(vcnt);  // (valid in lane 0, the only lane that uses it)
   T += (uint32_t)wave_sum_u32(tcnt);
-#endif
   if (lane == 0) {
     DevCounters* cs = ctr + (blockIdx.x % JADE_CTR_SHARDS);
 #if JADE_TRACE_PROFILE
@@ -854,14 +663,18 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
 #ifndef JADE_LIGHT_WAVES
 #define JADE_LIGHT_WAVES 4
 #endif
+#ifndef JADE_LIGHT_REFILL_MIN
+#define JADE_LIGHT_REFILL_MIN 32 /* waiting lanes of a wave that trigger k_light's shading block */
+#endif
 __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_LIGHT_WAVES) void k_light(DevScene S, PathState P, RenderConst R, const int32_t* tile_ids,
                                                                             uint32_t target_spp, uint32_t* heavy_regions, uint32_t region_cap,
                                                                             uint32_t* wave_counts, uint32_t* spill, DevCounters* ctr) {
-  __shared__ uint32_t lds_cols[JADE_CTX_WORDS * JADE_TRACE_BLOCK];
+  __shared__ __attribute__((aligned(JADE_COLS_ALIGN))) uint32_t lds_cols[JADE_CTX_WORDS * JADE_TRACE_BLOCK];
   __shared__ uint32_t sh_ctr[JADE_TRACE_BLOCK / 64][8];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   LdsStack stk;
   stk.lds = lds_cols + threadIdx.x;
+  stk.col = lds_addr_of(stk.lds);
   stk.spill = spill + (blockIdx.x * blockDim.x + threadIdx.x);
   stk.stride_spill = gridDim.x * blockDim.x;
   stk.top = nullptr;
@@ -870,7 +683,7 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_LIGHT_WAVES) void k_light(De
   __shared__ float4 lds_top[4 * JADE_LDS_TOP_NODES];
   {
     const uint32_t k = S.top_k;
-    for (uint32_t i = threadIdx.x; i < 4u * k; i += JADE_TRACE_BLOCK) lds_top[(i & 3u) * k + (i >> 2)] = S.nodes[i];
+    for (uint32_t i = threadIdx.x; i < 4u * k; i += JADE_TRACE_BLOCK) lds_top[(i & 3u) * JADE_LDS_TOP_NODES + (i >> 2)] = S.nodes[i];
     __syncthreads();
     stk.top = lds_top;
     stk.top_k = k;
@@ -923,21 +736,17 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_LIGHT_WAVES) void k_light(De
     bool finished = false;
     jvec3 color = jv(0, 0, 0), l_final = jv(0, 0, 0);
     // A lane is tracing (`active`), or waits to be shaded: its ray's result folded in and the next ray set up.  Shading
-    // runs for >= JADE_REFILL_MIN waiting lanes at a time (or when nothing is being traced): it is k_trace's refill, with
+    // runs for >= JADE_LIGHT_REFILL_MIN waiting lanes at a time (or when nothing is being traced): it is k_trace's refill, with
     // the next ray coming from the lane's own path instead of from a queue.
     bool active = false;   // a ray in flight
     bool pending = false;  // its result has not been folded in yet
     RayState r;
-    r.cur = JADE_REF_NONE;
-    r.leaf = 0;
-    r.sp = r.fw = r.fr = 0;
-    r.skipx = 0;
-    r.od.a = r.od.b = r.od.c = f2{0.0f, 0.0f};
+    ray_clear(r, stk);
     for (;;) {
       const unsigned long long tracing = __ballot(active);
       const int n_wait = __popcll(__ballot(mine && !active));
       if (tracing == 0ull && n_wait == 0) break;  // every lane is out of samples or parked
-      if (n_wait >= JADE_REFILL_MIN || tracing == 0ull) {
+      if (n_wait >= JADE_LIGHT_REFILL_MIN || tracing == 0ull) {
         if (mine && !active) {
           // ---- fold the result in (shade_record's part (a))
           if (pending) {
@@ -1040,7 +849,7 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_LIGHT_WAVES) void k_light(De
         const bool cw = active && ray_can_walk(r), ct = active && ray_can_test(r);
         const int nw = __popcll(__ballot(cw)), nt = __popcll(__ballot(ct));
         if (JADE_COST_TRI * nw >= JADE_COST_NODE * nt) {
-          if (__ballot(active && (int32_t)r.skipx < 0) != 0ull) {
+          if (S.general_walk || __ballot(active && (int32_t)r.skipx < 0) != 0ull) {
 #pragma nounroll
             for (int rep = 0; rep < JADE_STEPS_PER_PICK; ++rep)
               if (active && ray_can_walk(r)) ray_step_node_s<true>(r, S, stk, vcnt);
@@ -1470,7 +1279,6 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
     for (int i = 1; i < nN; ++i)
       if (d->nodes[i].n <= 0 && compact[i] < 0) compact[i] = n_internal++;
   }
-#if JADE_PAIR
   // vertex records hold two consecutive triangles of a leaf each (jade_trace.h): number the pairs leaf by leaf
   std::vector<uint32_t> pair_first(nN, 0);
   size_t n_pairs = 0;
@@ -1485,21 +1293,18 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
     }
     if (n_pairs * 5 >= ((size_t)1 << 27)) return fail(JADE_ERR_UNSUPPORTED, "too many triangle pairs for the 27-bit leaf cursor");
   }
-#endif
   auto ref_of = [&](int child) -> uint32_t {
     if (child <= 0) return JADE_REF_NONE;
     const jade_bvh_node& c = d->nodes[child];
-#if JADE_PAIR
     if (c.n > 0) return JADE_REF_LEAF | ((pair_first[child] * 5u) << 4) | (uint32_t)((c.n + 1) / 2);  // bits 4-30: byte offset / 16 of the first pair record
-#else
-    if (c.n > 0) return JADE_REF_LEAF | ((uint32_t)c.index * 3u << 4) | (uint32_t)c.n;  // bits 4-30: byte offset of the first vertex record
-#endif
     return (uint32_t)compact[child];
   };
   std::vector<float4> nodes((size_t)4 * std::max(n_internal, 1));
+  bool missing_child = false;  // the reference's "child 0" under an internal node: the walk then needs its general form
   for (int i = 1; i < nN; ++i) {
     const jade_bvh_node& nd = d->nodes[i];
     if (nd.n > 0) continue;
+    if (nd.left <= 0 || nd.right <= 0) missing_child = true;
     float la[3] = {0, 0, 0}, lb[3] = {0, 0, 0}, ra[3] = {0, 0, 0}, rb[3] = {0, 0, 0};
     if (nd.left > 0) { memcpy(la, d->nodes[nd.left].aa, 12); memcpy(lb, d->nodes[nd.left].bb, 12); }
     if (nd.right > 0) { memcpy(ra, d->nodes[nd.right].aa, 12); memcpy(rb, d->nodes[nd.right].bb, 12); }
@@ -1510,7 +1315,6 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
     uint32_t refs[4] = {ref_of(nd.left), ref_of(nd.right), 0u, 0u};
     memcpy(&o[3], refs, 16);
   }
-#if JADE_PAIR
   std::vector<float4> tverts((size_t)5 * std::max<size_t>(n_pairs, 1));
   for (int i = 1; i < nN; ++i) {
     const jade_bvh_node& nd = d->nodes[i];
@@ -1529,15 +1333,6 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
       o[4] = make_float4(a.p3[2], b.p3[2], tagf[0], tagf[1]);
     }
   }
-#else
-  std::vector<float4> tverts((size_t)3 * d->n_triangles);
-  for (int i = 0; i < d->n_triangles; ++i) {
-    const jade_triangle& t = d->triangles[i];
-    tverts[3 * (size_t)i] = make_float4(t.p1[0], t.p2[0], t.p1[1], t.p2[1]);
-    tverts[3 * (size_t)i + 1] = make_float4(t.p1[2], t.p2[2], t.p3[0], t.p3[1]);
-    tverts[3 * (size_t)i + 2] = make_float4(t.p3[2], 0.0f, 0.0f, 0.0f);
-  }
-#endif
 
   jade_scene* s = new (std::nothrow) jade_scene();
   if (!s) return fail(JADE_ERR_NOMEM, "out of memory");
@@ -1573,6 +1368,7 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
   s->dev.n_emit = d->n_emit;
   s->dev.root_ref = ref_of(1);
   s->dev.top_k = (uint32_t)std::min(n_internal, (int)JADE_LDS_TOP_NODES);
+  s->dev.general_walk = missing_child ? 1u : 0u;
 
   // the arithmetic contract of jade_fpmath.h, checked on the device once
   hipLaunchKernelGGL(k_selftest, dim3(1), dim3(1), 0, s->stream, s->b_ctl.as<QueueCtl>(), 1.0f);
@@ -1652,7 +1448,7 @@ static int setup_state(jade_scene* s, int npx, int rpp, int nslots) {
   HIP_TRY(s->b_active[1].alloc(N * 4));
   HIP_TRY(s->b_wavecnt.alloc((size_t)2 * s->light_blocks * (JADE_TRACE_BLOCK / 64) * 4));
   if (!s->b_spill.p)
-    HIP_TRY(s->b_spill.alloc((size_t)JADE_TRACE_CTXS * (JADE_BVH_STACK_CAPACITY - JADE_LDS_STACK) * s->trace_blocks * JADE_TRACE_BLOCK * 4));
+    HIP_TRY(s->b_spill.alloc((size_t)(JADE_BVH_STACK_CAPACITY - JADE_LDS_STACK) * s->trace_blocks * JADE_TRACE_BLOCK * 4));
   return JADE_OK;
 }
 
@@ -2269,7 +2065,7 @@ int jade_trace_rays(jade_scene* s, int32_t n, const float* origins, const float*
   HIP_TRY(b_hdist.alloc(N * 4));
   HIP_TRY(hipMemsetAsync(b_hpt.p, 0, 3 * N * 4, s->stream));  // the hit point of a miss is never written: report zeros
   HIP_TRY(upload(b_q, q.data(), N, s->stream));
-  HIP_TRY(b_spill.alloc((size_t)JADE_TRACE_CTXS * (JADE_BVH_STACK_CAPACITY - JADE_LDS_STACK) * s->trace_blocks * JADE_TRACE_BLOCK * 4));
+  HIP_TRY(b_spill.alloc((size_t)(JADE_BVH_STACK_CAPACITY - JADE_LDS_STACK) * s->trace_blocks * JADE_TRACE_BLOCK * 4));
   PathState P{};
   P.npix = n;
   P.nslots = 1;

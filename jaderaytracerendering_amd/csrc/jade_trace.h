@@ -42,27 +42,33 @@ struct TraceHit {
 #ifndef JADE_ABLATE_TRI
 #define JADE_ABLATE_TRI 0
 #endif
-#ifndef JADE_ABLATE_HIT
-#define JADE_ABLATE_HIT 0
-#endif
 #ifndef JADE_ABLATE_SLAB
 #define JADE_ABLATE_SLAB 0
 #endif
 #ifndef JADE_ABLATE_LOAD
 #define JADE_ABLATE_LOAD 0
 #endif
-#ifndef JADE_PAIR
-#define JADE_PAIR 1 /* triangle tests two at a time, packed across the two triangles (pair records, below) */
-#endif
 
-// A lane's column of LDS words, lds[word * JADE_TRACE_BLOCK + tid] (bank-conflict free):
-// words [0, JADE_LDS_STACK) are the traversal stack, the JADE_LDS_STATE words after it hold
-// the parts of the ray state that the triangle test does not read (see RayState).
+// A lane's column of LDS words, word k of lane t at byte  k * JADE_COL_STRIDE + 4 t  of the block's column array
+// (bank-conflict free): words [0, JADE_LDS_STACK) are the traversal stack, then the leaf FIFO, then the JADE_LDS_STATE
+// words that hold the parts of the ray state the triangle test does not read (see RayState).
+//
+// The node step is bound by instruction issue, and a third of it was address arithmetic for these words (index -> * 256
+// -> select -> * 4 + base, per access).  So positions are kept AS LDS byte addresses: the stack pointer is the address
+// of the next free level, the FIFO counters advance in units of one column word, and the column array is 4 KB-aligned
+// so that a FIFO slot's address is one v_and_or of the counter and the FIFO's base.
+#define JADE_COL_STRIDE (4u * JADE_TRACE_BLOCK) /* bytes between two words of a lane's column */
+typedef __attribute__((address_space(3))) uint32_t jade_lds_u32;
+static __device__ __forceinline__ uint32_t lds_addr_of(const uint32_t* p) { return (uint32_t)(__SIZE_TYPE__)(jade_lds_u32*)p; }
+static __device__ __forceinline__ void lds_st(uint32_t addr, uint32_t v) { *(jade_lds_u32*)(__SIZE_TYPE__)addr = v; }
+static __device__ __forceinline__ uint32_t lds_ld(uint32_t addr) { return *(jade_lds_u32*)(__SIZE_TYPE__)addr; }
+
 struct LdsStack {
-  uint32_t* lds;       // base of this lane's column
+  uint32_t* lds;       // this lane's column (word k at lds[k * JADE_TRACE_BLOCK])
+  uint32_t col;        // the same as an LDS byte address
   uint32_t* spill;     // global, spill[(level - JADE_LDS_STACK) * stride + gtid]
   uint32_t stride_spill;
-  const float4* top;   // LDS copy of node records [0, top_k): four planes of top_k float4 (plane j = the record's j-th 16 bytes)
+  const float4* top;   // LDS copy of node records [0, top_k): four planes of JADE_LDS_TOP_NODES float4 (plane j = the record's j-th 16 bytes)
   uint32_t top_k;
 };
 enum {
@@ -73,25 +79,14 @@ enum {
 };
 static_assert(LW_END - LW_INVX == JADE_LDS_STATE, "JADE_LDS_STATE must count the LW_* state words");
 static_assert((JADE_LDS_FIFO & (JADE_LDS_FIFO - 1)) == 0, "JADE_LDS_FIFO must be a power of two");
+static_assert(JADE_LDS_STACK % JADE_LDS_FIFO == 0, "the FIFO's first word must be a multiple of its size (slot address = base | counter bits)");
+#define JADE_FIFO_MASK ((JADE_LDS_FIFO - 1u) * JADE_COL_STRIDE)
+#define JADE_COLS_ALIGN (JADE_LDS_FIFO * JADE_COL_STRIDE) /* alignment of the block's column array */
 
-static __device__ __forceinline__ void lds_put(const LdsStack& s, int word, uint32_t v) { s.lds[word * JADE_TRACE_BLOCK] = v; }
-static __device__ __forceinline__ uint32_t lds_get(const LdsStack& s, int word) { return s.lds[word * JADE_TRACE_BLOCK]; }
+static __device__ __forceinline__ void lds_put(const LdsStack& s, int word, uint32_t v) { lds_st(s.col + (uint32_t)word * JADE_COL_STRIDE, v); }
+static __device__ __forceinline__ uint32_t lds_get(const LdsStack& s, int word) { return lds_ld(s.col + (uint32_t)word * JADE_COL_STRIDE); }
 static __device__ __forceinline__ void lds_putf(const LdsStack& s, int word, float v) { lds_put(s, word, jade_f2u(v)); }
 static __device__ __forceinline__ float lds_getf(const LdsStack& s, int word) { return jade_u2f(lds_get(s, word)); }
-
-static __device__ __forceinline__ void stack_push(const LdsStack& s, int sp, uint32_t v) {
-  if (sp < JADE_LDS_STACK) s.lds[sp * JADE_TRACE_BLOCK] = v;
-  else s.spill[(size_t)(sp - JADE_LDS_STACK) * s.stride_spill] = v;
-}
-static __device__ __forceinline__ uint32_t stack_pop(const LdsStack& s, int sp) {
-  // The LDS level is read unconditionally and made opaque: written as "LDS or global", the two loads become ONE flat
-  // load through a selected generic pointer, and every pop then travels the vector-memory address path (the unit
-  // k_trace is bound by) instead of being a plain ds_read.
-  uint32_t v = s.lds[(sp < JADE_LDS_STACK ? sp : 0) * JADE_TRACE_BLOCK];
-  asm volatile("" : "+v"(v));
-  if (sp >= JADE_LDS_STACK) v = s.spill[(size_t)(sp - JADE_LDS_STACK) * s.stride_spill];
-  return v;
-}
 
 // Two lanes of packed fp32 (v_pk_add/mul/fma_f32: full rate, IEEE per component, so the
 // values are those of the scalar statements).  The kernel is VALU-bound; the left/right slab
@@ -149,54 +144,6 @@ static __device__ __forceinline__ void slab2(const RayOD& od, jvec3 inv, float4 
   *d2 = slab_reduce(fx.y, fy.y, fz.y, nx.y, ny.y, nz.y, exact);
 }
 
-// hitTriangle, PathTrace.cu:705-754, with normalize(dir) hoisted.  The vertex record comes as
-// loaded (jade_device.h): q0 = {p1.x, p2.x, p1.y, p2.y}, q1 = {p1.z, p2.z}, p3 apart.  Lane .x of
-// every pair is the statement for p1 (or for papb), lane .y the same statement for p2 (pbpc).
-static __device__ __forceinline__ bool tri_test(float4 q0, float2 q1, jvec3 p3, const RayOD& od, float* dist_out, jvec3* point_out) {
-  const jvec3 o = od_o(od), dn = od_dn(od);
-  const f2 Ax = {q0.x, q0.y}, Ay = {q0.z, q0.w}, Az = {q1.x, q1.y};
-  // sa|sb = p - dn * dot(dn, p - o)    (jv_dot: fma(a.z, b.z, fma(a.y, b.y, a.x * b.x)))
-  const f2 tA = f2fma(OD_DZ(od), Az - OD_OZ(od), f2fma(OD_DY(od), Ay - OD_OY(od), OD_DX(od) * (Ax - OD_OX(od))));
-  const f2 sx = Ax - OD_DX(od) * tA, sy = Ay - OD_DY(od) * tA, sz = Az - OD_DZ(od) * tA;
-  const jvec3 sc = jv_sub(p3, jv_scale(dn, jv_dot(dn, jv_sub(p3, o))));
-  // pa|pb = s - o, pc
-  const f2 px = sx - OD_OX(od), py = sy - OD_OY(od), pz = sz - OD_OZ(od);
-  const jvec3 pc = jv_sub(sc, o);
-  // papb|pbpc = mixed(dn, pa|pb, pb|pc)   (jv_mixed / jade_diffprod: fma(a, b, -(c * d)))
-  const f2 cx = {px.y, pc.x}, cy = {py.y, pc.y}, cz = {pz.y, pc.z};
-  f2 m = OD_DX(od) * f2fma(py, cz, -(pz * cy));
-  m = f2fma(OD_DY(od), f2fma(pz, cx, -(px * cz)), m);
-  m = f2fma(OD_DZ(od), f2fma(px, cy, -(py * cx)), m);
-  const float papb = m.x, pbpc = m.y;
-  const float pcpa = jv_mixed(dn, pc, jv(px.x, py.x, pz.x));
-  if ((papb > 0 && pbpc > 0 && pcpa > 0) || (papb < 0 && pbpc < 0 && pcpa < 0)) {
-    const jvec3 p1 = jv(q0.x, q0.z, q1.x), p2 = jv(q0.y, q0.w, q1.y);
-    const jvec3 sa = jv(sx.x, sy.x, sz.x), sb = jv(sx.y, sy.y, sz.y);
-    jvec3 eb = jv_sub(sb, sa), ec = jv_sub(sc, sa), q = jv_sub(o, sa);
-    float divider = jade_diffprod(eb.x, ec.y, eb.y, ec.x);
-    float rate_a = jade_diffprod(ec.y, q.x, ec.x, q.y) / divider;
-    float rate_b = jade_fma(eb.x, q.y, (-eb.y) * q.x) / divider;
-    jvec3 P = jv_add(jv_add(p1, jv_scale(jv_sub(p2, p1), rate_a)), jv_scale(jv_sub(p3, p1), rate_b));
-    float distance = jv_dot(jv_sub(P, o), dn);
-#if JADE_ABLATE_HIT
-    {  // the same block again on nudged operands: prices the hit path
-      jvec3 q2 = jv_sub(jv(o.x + 1e-30f, o.y, o.z), sa);
-      float ra2 = jade_diffprod(ec.y, q2.x, ec.x, q2.y) / divider;
-      float rb2 = jade_fma(eb.x, q2.y, (-eb.y) * q2.x) / divider;
-      jvec3 P2 = jv_add(jv_add(p1, jv_scale(jv_sub(p2, p1), ra2)), jv_scale(jv_sub(p3, p1), rb2));
-      float d2 = jv_dot(jv_sub(P2, o), dn);
-      asm volatile("" ::"v"(d2));
-    }
-#endif
-    if (distance > 0) {
-      *dist_out = distance;
-      *point_out = P;
-      return true;
-    }
-  }
-  return false;
-}
-
 static __device__ __forceinline__ bool finite_f(float x) { return (jade_f2u(x) & 0x7f800000u) != 0x7f800000u; }
 
 // One lane's traversal state for hitBVH (PathTrace.cu:795-859).
@@ -212,28 +159,20 @@ static __device__ __forceinline__ bool finite_f(float x) { return (jade_f2u(x) &
 // leaves waiting can always join.  The kernel is VALU-bound: with the kinds interleaved per
 // lane, as in a plain loop over hitBVH, each instruction runs for about a third of the lanes.
 //
-// State is cut to what fits 64 VGPRs (8 waves/SIMD).  In registers: o, normalize(d), the skip
-// offset, the node cursor, the leaf cursor, and one word of counters (stack pointer, FIFO
-// head, FIFO count).  In the lane's LDS column: the stack, the FIFO, 1/d (read by node visits
-// only) and the best hit so far (touched only when a triangle is actually hit).
-// A leaf cursor is the leaf reference itself: LEAF | 3 * first << 4 | count.  Bits 4-30 are the
-// byte offset of the next triangle's 48-B vertex record, so a test needs one AND to address it
-// and +47 to advance (offset + 48, count - 1); triangles are identified by that offset until
-// the ray ends.
-struct V3ld {
-  float x, y, z;
-};
+// In registers: o, normalize(d), the skip index, the node cursor, the leaf cursor, the stack pointer and the FIFO
+// counters.  In the lane's LDS column: the stack, the FIFO, 1/d (read by node visits only) and the best hit so far
+// (touched only when a triangle is actually hit).
+// A leaf cursor is the leaf reference itself: LEAF | 5 * first_pair << 4 | pairs.  Bits 4-30 are the byte offset of
+// the next 80-B pair record (ray_step_tri_s), so a test needs one AND to address it and +79 to advance (offset + 80,
+// one pair fewer).
 struct RayState {
   RayOD od;        // origin and normalize(d)
-  uint32_t skipx;  // bit 31: a component of o or 1/d is not finite (NaN-faithful slab needed); bits 0-30: 48 * source triangle, 0x7fffffff = none
+  uint32_t skipx;  // bit 31: a component of o or 1/d is not finite (NaN-faithful slab needed); bits 0-30: the source triangle, 0x7fffffff = none
   uint32_t cur;    // node walk: internal-node ref, a leaf ref not yet queued, or JADE_REF_NONE = walk finished
   uint32_t leaf;   // triangle tests: cursor of the leaf being tested, 0 = none (then the FIFO is empty too)
-  // (one word used to pack these three: unpacking and repacking it was a dozen instructions per step of a VALU-bound kernel)
-  uint32_t sp;     // stack pointer
-  uint32_t fw, fr; // leaf FIFO: cursors written / read so far (slot = counter & (JADE_LDS_FIFO - 1))
+  uint32_t sp;     // stack pointer: LDS byte address of the next free level (stk.col = empty)
+  uint32_t fw, fr; // leaf FIFO: cursors written / read so far, in units of JADE_COL_STRIDE (slot address = FIFO base | (counter & JADE_FIFO_MASK))
 };
-#define RS_SP(r) ((r).sp)
-#define RS_FIFO_N(r) ((r).fw - (r).fr)
 
 static __device__ __forceinline__ void ray_begin(RayState& r, const LdsStack& stk, const DevScene& S, jvec3 o, jvec3 d, int32_t skip) {
   const jvec3 inv = jv(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
@@ -242,12 +181,9 @@ static __device__ __forceinline__ void ray_begin(RayState& r, const LdsStack& st
   r.od.b = f2{o.z, dn.x};
   r.od.c = f2{dn.y, dn.z};
   const bool exact = !(finite_f(inv.x) && finite_f(inv.y) && finite_f(inv.z)) || !finite_f(o.x) || !finite_f(o.y) || !finite_f(o.z);
-#if JADE_PAIR
   r.skipx = (skip < 0 ? 0x7fffffffu : (uint32_t)skip) | (exact ? 0x80000000u : 0u);  // pair records carry triangle indices
-#else
-  r.skipx = (skip < 0 ? 0x7fffffffu : (uint32_t)skip * 48u) | (exact ? 0x80000000u : 0u);
-#endif
-  r.sp = r.fw = r.fr = 0;
+  r.sp = stk.col;
+  r.fw = r.fr = 0;
   r.leaf = 0;
   r.cur = S.root_ref;
   lds_putf(stk, LW_INVX, inv.x);
@@ -256,225 +192,68 @@ static __device__ __forceinline__ void ray_begin(RayState& r, const LdsStack& st
   lds_putf(stk, LW_BEST_DIST, JADE_INF_F);
   lds_put(stk, LW_BEST_INDEX, 0xffffffffu);
 }
+// a lane that holds no ray
+static __device__ __forceinline__ void ray_clear(RayState& r, const LdsStack& stk) {
+  r.cur = JADE_REF_NONE;
+  r.leaf = 0;
+  r.sp = stk.col;
+  r.fw = r.fr = 0;
+  r.skipx = 0;
+  r.od.a = r.od.b = r.od.c = f2{0.0f, 0.0f};
+}
 
-static __device__ __forceinline__ bool ray_walking(const RayState& r) { return r.cur != JADE_REF_NONE; }
 static __device__ __forceinline__ bool ray_done(const RayState& r) { return r.cur == JADE_REF_NONE && r.leaf == 0; }
 // room for one more leaf cursor
-static __device__ __forceinline__ bool leaf_room(const RayState& r) { return r.leaf == 0 || RS_FIFO_N(r) < JADE_LDS_FIFO; }
+static __device__ __forceinline__ bool leaf_room(const RayState& r) { return r.leaf == 0 || r.fw - r.fr < JADE_LDS_FIFO * JADE_COL_STRIDE; }
 // a lane can take part in a node iteration / a triangle iteration
 static __device__ __forceinline__ bool ray_can_walk(const RayState& r) {
   return r.cur != JADE_REF_NONE && (!(r.cur & JADE_REF_LEAF) || leaf_room(r));
 }
 static __device__ __forceinline__ bool ray_can_test(const RayState& r) { return r.leaf != 0; }
 
-// the walk's next reference: top of the stack, or JADE_REF_NONE when it is empty
-static __device__ __forceinline__ uint32_t walk_pop(RayState& r, const LdsStack& stk) {
-  if (RS_SP(r) == 0) return JADE_REF_NONE;
-  r.sp -= 1u;
-  return stack_pop(stk, (int)RS_SP(r));
-}
-static __device__ __forceinline__ void leaf_queue(RayState& r, const LdsStack& stk, uint32_t ref) {
-  if ((ref & 15u) == 0) return;  // empty leaf: cannot happen for a valid BVH
-  if (r.leaf == 0) {
-    r.leaf = ref;
-  } else {
-    const uint32_t slot = r.fw & (JADE_LDS_FIFO - 1);
-    lds_put(stk, LW_FIFO + (int)slot, ref);
-    r.fw += 1u;
-  }
-}
-
-static __device__ __forceinline__ int32_t ray_best_index(const LdsStack& stk) {
-  const uint32_t off = lds_get(stk, LW_BEST_INDEX);  // byte offset of the vertex record (JADE_PAIR: the triangle index), or ~0
-#if JADE_PAIR
-  return (int32_t)off;  // ~0 is -1
-#else
-  return off == 0xffffffffu ? -1 : (int32_t)(off / 48u);
-#endif
-}
+static __device__ __forceinline__ int32_t ray_best_index(const LdsStack& stk) { return (int32_t)lds_get(stk, LW_BEST_INDEX); }  // triangle index, ~0 = -1 = miss
 static __device__ __forceinline__ jvec3 ray_hit_point(const LdsStack& stk) {
   return jv(lds_getf(stk, LW_PX), lds_getf(stk, LW_PY), lds_getf(stk, LW_PZ));
 }
 
-// One triangle of the leaf at the head of the FIFO (hitArray, PathTrace.cu:776-792), in index order.
-// Call only if ray_can_test.  *tested: an intersection test ran (the skipped source triangle does not count).
-static __device__ __forceinline__ void ray_step_tri(RayState& r, const DevScene& S, const LdsStack& stk, bool* tested) {
-  const uint32_t off = r.leaf & 0x7ffffff0u;
-  // saddr + 32-bit voffset loads of the 36 used bytes of the record
-  const char* t0 = reinterpret_cast<const char*>(S.tverts) + off;
-  const float4 q0 = *reinterpret_cast<const float4*>(t0);
-  const float2 q1 = *reinterpret_cast<const float2*>(t0 + 16);
-  const V3ld q3 = *reinterpret_cast<const V3ld*>(t0 + 24);
-  const jvec3 p3 = jv(q3.x, q3.y, q3.z);
-  r.leaf += 47u;  // next record, count - 1
-#if JADE_ABLATE_TRI
-  {
-    float d2; jvec3 P2;
-    RayOD o2 = r.od;
-    o2.a.x += 1e-30f;
-    bool h2 = tri_test(q0, q1, p3, o2, &d2, &P2);
-    asm volatile("" ::"v"(h2 ? d2 + P2.x : 0.0f));
-  }
-#endif
-  if (off != (r.skipx & 0x7fffffffu)) {
-    *tested = true;
-    float dist;
-    jvec3 P;
-    if (tri_test(q0, q1, p3, r.od, &dist, &P) &&
-        dist < lds_getf(stk, LW_BEST_DIST)) {
-      lds_putf(stk, LW_BEST_DIST, dist);
-      lds_put(stk, LW_BEST_INDEX, off);
-      lds_putf(stk, LW_PX, P.x);
-      lds_putf(stk, LW_PY, P.y);
-      lds_putf(stk, LW_PZ, P.z);
-    }
-  }
-  if ((r.leaf & 15u) == 0) {  // leaf finished: next one from the FIFO
-    if (RS_FIFO_N(r)) {
-      const uint32_t head = r.fr & (JADE_LDS_FIFO - 1);
-      r.leaf = lds_get(stk, LW_FIFO + (int)head);
-      r.fr += 1u;
-    } else {
-      r.leaf = 0;
-    }
-  }
-}
-
-// One unit of the node walk.  Call only if ray_can_walk.  A leaf reference in `cur` is queued and
-// replaced by the next reference; an internal node is visited: both children's slab tests,
-// near-first descent (PathTrace.cu:835-848), the far child pushed.  *c1, *c2: the child exists (its
-// record counts as visited).
-static __device__ __forceinline__ void ray_step_node(RayState& r, const DevScene& S, const LdsStack& stk, bool* c1, bool* c2) {
-  // One queue site and one pop site for every way a step can need them (a leaf left over from a step
-  // that found the FIFO full, the near child being a leaf, the only entered child being a leaf, no child
-  // entered): code that exists once runs once per step, for all the lanes that need it together.
-  uint32_t cur = r.cur;
-  uint32_t leafv = 0;     // leaf met by this step (queued below)
-  bool need_pop = false;  // the walk continues from the stack
-  if (cur & JADE_REF_LEAF) {  // left over (room was checked by ray_can_walk)
-    leafv = cur;
-    need_pop = true;
-  } else {
-    float4 a, b, c;
-    uint2 rf;
-#if JADE_LDS_TOP_NODES > 0
-    // The top of the tree lives in LDS, one plane per 16 bytes of the record (lane addresses 16 B apart spread over all
-    // 64 banks of a ds_read_b128); these visits - the most frequent ones - stay out of the vector-memory path.  Every
-    // lane reads LDS (a lane below the top reads entry 0: LDS bandwidth is idle) and only the lanes below the top issue
-    // global loads, into registers of their own: one `if` with both kinds of pointer in it makes the compiler fall back
-    // to per-dword FLAT loads for everything (12 loads per visit instead of 4).
-    const bool in_top = cur < stk.top_k;
-    const float4* t = stk.top + (in_top ? cur : 0u);
-    const float4 la = t[0], lb = t[stk.top_k], lc = t[2 * stk.top_k], lr = t[3 * stk.top_k];
-    float4 ga = la, gb = lb, gc = lc;
-    uint2 grf = make_uint2(jade_f2u(lr.x), jade_f2u(lr.y));
-    // (opaque to the optimiser, or it turns "LDS value, overwritten by a global load for some lanes" back into one load
-    // through a selected generic pointer)
-    asm volatile("" : "+v"(ga.x), "+v"(ga.y), "+v"(ga.z), "+v"(ga.w), "+v"(gb.x), "+v"(gb.y), "+v"(gb.z), "+v"(gb.w));
-    asm volatile("" : "+v"(gc.x), "+v"(gc.y), "+v"(gc.z), "+v"(gc.w), "+v"(grf.x), "+v"(grf.y));
-    if (!in_top) {
-      const float4* nd = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.nodes) + cur * 64u);
-      ga = nd[0];
-      gb = nd[1];
-      gc = nd[2];
-      grf = *reinterpret_cast<const uint2*>(nd + 3);
-#if JADE_ABLATE_LOAD
-      {  // prices the vector-memory path: one more 16-B gather per lane from the line just fetched (+25 % look-ups, same bytes from L2)
-        const float4 x = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(nd) + 40);
-        asm volatile("" ::"v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w));
-      }
-#endif
-    }
-    a = ga;
-    b = gb;
-    c = gc;
-    rf = grf;
-#else
-    {
-      const float4* nd = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.nodes) + cur * 64u);
-      a = nd[0];
-      b = nd[1];
-      c = nd[2];
-      rf = *reinterpret_cast<const uint2*>(nd + 3);
-    }
-#endif
-    const jvec3 inv = jv(lds_getf(stk, LW_INVX), lds_getf(stk, LW_INVY), lds_getf(stk, LW_INVZ));
-    const bool exact = (int32_t)r.skipx < 0;
-    float d1 = -1.0f, d2 = -1.0f;
-#if JADE_ABLATE_SLAB
-    {
-      RayOD o2 = r.od;
-      o2.a.x += 1e-30f;
-      float e1, e2;
-      slab2(o2, inv, a, b, c, exact, &e1, &e2);
-      asm volatile("" ::"v"(e1 + e2));
-    }
-#endif
-    slab2(r.od, inv, a, b, c, exact, &d1, &d2);
-    *c1 = rf.x != JADE_REF_NONE;  // a missing child (the reference's index 0) is neither counted nor entered
-    *c2 = rf.y != JADE_REF_NONE;
-    if (!*c1) d1 = -1.0f;
-    if (!*c2) d2 = -1.0f;
-    const bool in1 = d1 > 0, in2 = d2 > 0;
-    const bool room = leaf_room(r);
-    if (in1 && in2) {  // near child first (d1 < d2, PathTrace.cu:835-848)
-      const bool first = d1 < d2;
-      const uint32_t near = first ? rf.x : rf.y, far = first ? rf.y : rf.x;
-      if ((near & JADE_REF_LEAF) && room) {  // the near leaf is met now; the far child is next, nothing to push
-        leafv = near;
-        cur = far;
-      } else {
-        stack_push(stk, (int)RS_SP(r), far);
-        r.sp += 1u;
-        cur = near;
-      }
-    } else if (in1 || in2) {
-      cur = in1 ? rf.x : rf.y;
-      if ((cur & JADE_REF_LEAF) && room) {
-        leafv = cur;
-        need_pop = true;
-      }
-    } else {
-      need_pop = true;
-    }
-  }
-  if (leafv) leaf_queue(r, stk, leafv);
-  if (need_pop) cur = walk_pop(r, stk);
-  r.cur = cur;  // may be a leaf (the far child, a popped one, or one that found no room): the next step queues it
-}
-
-
 // ---------------------------------------------------------------------------------------------------------------
-// Straight-line forms of the two steps (JADE_STRAIGHT, the default).  Same statements, same results; what changes
-// is that no decision is a branch.  k_trace is bound by instruction issue, and the nested ifs above cost it twice:
-// every `if` is 3-4 scalar instructions of EXEC bookkeeping in the wave's (serial) instruction stream - scalar and
-// branch instructions were 40 % of all instructions issued - and each side of it runs for a part of the lanes only
-// (31.7 of 64 lanes per VALU instruction although 39 had work of the picked kind).  Here a decision selects values
-// (v_cndmask) and, where it guards a store, the store's ADDRESS: a lane the statement does not apply to writes its
-// column's LW_DUMMY word (LDS is 7 % busy).  Only the rare cases stay branches: a stack deeper than its LDS levels
-// (0.4 % of the rays) and a triangle that is actually hit.
+// The two steps, straight-line.  k_trace is bound by instruction issue, and nested ifs cost it twice: every `if` is 3-4
+// scalar instructions of EXEC bookkeeping in the wave's (serial) instruction stream - scalar and branch instructions
+// were 40 % of all instructions issued by the first, branchy form (round 1; git history) - and each side of it runs for
+// a part of the lanes only.  Here a decision selects values (v_cndmask) and, where it guards a store, the store's
+// ADDRESS: a lane the statement does not apply to writes its column's LW_DUMMY word (LDS is 7 % busy).  Only the rare
+// cases stay branches: a stack deeper than its LDS levels (0.4 % of the rays) and a triangle that is actually hit.
 // ---------------------------------------------------------------------------------------------------------------
-static __device__ __forceinline__ void lds_put_w(const LdsStack& s, uint32_t word, uint32_t v) { s.lds[word * JADE_TRACE_BLOCK] = v; }
-static __device__ __forceinline__ uint32_t lds_get_w(const LdsStack& s, uint32_t word) { return s.lds[word * JADE_TRACE_BLOCK]; }
 
-// One unit of the node walk for a lane with ray_can_walk.  vcnt: this lane's count of child records visited.
-template <bool EXACT>
+// One unit of the node walk for a lane with ray_can_walk: a leaf reference in `cur` (the far child of an earlier visit
+// coming off the stack, or a leaf that found the FIFO full) is queued and replaced by the next reference; an internal
+// node is visited: both children's slab tests, near-first descent (PathTrace.cu:835-848), the far child pushed.
+// vcnt: this lane's count of child records visited.
+// GENERAL = false leaves out what almost no wave needs (decided per wave, a scalar branch in the caller): the
+// NaN-faithful slab reduction (a ray with a non-finite 1/d or origin) and children that do not exist (the reference's
+// "child 0"; jade_scene_create tells whether the tree has any).
+template <bool GENERAL>
 static __device__ __forceinline__ void ray_step_node_s(RayState& r, const DevScene& S, const LdsStack& stk, uint32_t& vcnt) {
   const uint32_t cur = r.cur;
-  const bool is_leaf = (cur & JADE_REF_LEAF) != 0;  // left over from a step that could not queue it (room was checked by ray_can_walk)
-  const uint32_t node = is_leaf ? 0u : cur;         // such a lane reads record 0 and ignores it
+  const bool is_leaf = (int32_t)cur < 0;
+  const uint32_t node = is_leaf ? 0u : cur;  // such a lane reads record 0 and ignores it
   float4 a, b, c;
   uint2 rf;
 #if JADE_LDS_TOP_NODES > 0
   {
+    // The top of the tree lives in LDS, one plane per 16 bytes of the record (lane addresses 16 B apart spread over all
+    // 64 banks of a ds_read_b128); these visits - the most frequent ones - stay out of the vector-memory path.  Every
+    // lane reads LDS (a lane below the top reads entry 0: LDS bandwidth is idle) and only the lanes below the top issue
+    // global loads.  The LDS values are made opaque: written as "LDS or global", the loads become per-dword FLAT loads
+    // through a selected generic pointer (12 loads per visit instead of 4).
     const bool in_top = node < stk.top_k;
     const float4* t = stk.top + (in_top ? node : 0u);
-    const float4 la = t[0], lb = t[stk.top_k], lc = t[2 * stk.top_k], lr = t[3 * stk.top_k];
+    const float4 la = t[0], lb = t[JADE_LDS_TOP_NODES], lc = t[2 * JADE_LDS_TOP_NODES], lr = t[3 * JADE_LDS_TOP_NODES];
     a = la;
     b = lb;
     c = lc;
     rf = make_uint2(jade_f2u(lr.x), jade_f2u(lr.y));
-    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w));  // see ray_step_node
+    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w));
     asm volatile("" : "+v"(c.x), "+v"(c.y), "+v"(c.z), "+v"(c.w), "+v"(rf.x), "+v"(rf.y));
     if (!in_top) {
       const float4* nd = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.nodes) + node * 64u);
@@ -482,6 +261,12 @@ static __device__ __forceinline__ void ray_step_node_s(RayState& r, const DevSce
       b = nd[1];
       c = nd[2];
       rf = *reinterpret_cast<const uint2*>(nd + 3);
+#if JADE_ABLATE_LOAD
+      {  // prices the vector-memory path: one more 16-B gather per lane from the line just fetched (+25 % look-ups, same bytes from L2)
+        const float4 x = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(nd) + 40);
+        asm volatile("" ::"v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w));
+      }
+#endif
     }
   }
 #else
@@ -495,92 +280,76 @@ static __device__ __forceinline__ void ray_step_node_s(RayState& r, const DevSce
 #endif
   const jvec3 inv = jv(lds_getf(stk, LW_INVX), lds_getf(stk, LW_INVY), lds_getf(stk, LW_INVZ));
   float d1, d2;
-  slab2(r.od, inv, a, b, c, EXACT, &d1, &d2);
-  const bool c1 = !is_leaf && rf.x != JADE_REF_NONE, c2 = !is_leaf && rf.y != JADE_REF_NONE;  // a missing child is neither counted nor entered
-  vcnt += (c1 ? 1u : 0u) + (c2 ? 1u : 0u);
-  const bool in1 = c1 && d1 > 0, in2 = c2 && d2 > 0;
+#if JADE_ABLATE_SLAB
+  {
+    RayOD o2 = r.od;
+    o2.a.x += 1e-30f;
+    float e1, e2;
+    slab2(o2, inv, a, b, c, GENERAL, &e1, &e2);
+    asm volatile("" ::"v"(e1 + e2));
+  }
+#endif
+  slab2(r.od, inv, a, b, c, GENERAL, &d1, &d2);
+  bool in1, in2;
+  if (GENERAL) {
+    const bool c1 = !is_leaf && rf.x != JADE_REF_NONE, c2 = !is_leaf && rf.y != JADE_REF_NONE;  // a missing child is neither counted nor entered
+    vcnt += (c1 ? 1u : 0u) + (c2 ? 1u : 0u);
+    in1 = c1 && d1 > 0;
+    in2 = c2 && d2 > 0;
+  } else {
+    vcnt += is_leaf ? 0u : 2u;
+    in1 = !is_leaf && d1 > 0;
+    in2 = !is_leaf && d2 > 0;
+  }
   const bool both = in1 && in2, any = in1 || in2;
   const bool first = d1 < d2;  // near child first, PathTrace.cu:835-848
   const uint32_t near = both ? (first ? rf.x : rf.y) : (in1 ? rf.x : rf.y);
   const uint32_t far = first ? rf.y : rf.x;
-  const bool room = leaf_room(r);
-  const bool near_leaf_ok = any && (near & JADE_REF_LEAF) != 0 && room;  // the near leaf is met now
+  const bool near_leaf_ok = any && (int32_t)near < 0 && leaf_room(r);  // the near leaf is met now
   // both, near leaf met: the far child is next, nothing to push.  both otherwise: push far, go near.  one: go there (a
   // leaf that is met ends the branch: pop).  none: pop.
   const uint32_t leafv = is_leaf ? cur : (near_leaf_ok ? near : 0u);
   const bool push = both && !near_leaf_ok;
   const uint32_t next = both ? (near_leaf_ok ? far : near) : near;
   const bool need_pop = is_leaf || !any || (!both && near_leaf_ok);
-  // ---- leaf_queue
+  const uint32_t dummy = stk.col + LW_DUMMY * JADE_COL_STRIDE;
+  // ---- the leaf met goes to the leaf cursor, or behind it into the FIFO
   {
     const bool lq = (leafv & 15u) != 0;  // (an empty leaf cannot happen for a valid BVH)
     const bool to_fifo = lq && r.leaf != 0;
-    lds_put_w(stk, to_fifo ? (uint32_t)LW_FIFO + (r.fw & (JADE_LDS_FIFO - 1)) : (uint32_t)LW_DUMMY, leafv);
+    const uint32_t slot = (stk.col + LW_FIFO * JADE_COL_STRIDE) | (r.fw & JADE_FIFO_MASK);
+    lds_st(to_fifo ? slot : dummy, leafv);
     r.leaf = (lq && r.leaf == 0) ? leafv : r.leaf;
-    r.fw += to_fifo ? 1u : 0u;
+    r.fw += to_fifo ? JADE_COL_STRIDE : 0u;
   }
   // ---- push the far child
+  const uint32_t lds_end = stk.col + JADE_LDS_STACK * JADE_COL_STRIDE;  // address of the first level that is not in LDS
   uint32_t sp = r.sp;
-  lds_put_w(stk, (push && sp < JADE_LDS_STACK) ? sp : (uint32_t)LW_DUMMY, far);
-  if (push && sp >= JADE_LDS_STACK) stk.spill[(size_t)(sp - JADE_LDS_STACK) * stk.stride_spill] = far;  // rare
-  sp += push ? 1u : 0u;
+  lds_st((push && sp < lds_end) ? sp : dummy, far);
+  if (push && sp >= lds_end) stk.spill[(size_t)((sp - lds_end) / JADE_COL_STRIDE) * stk.stride_spill] = far;  // rare
+  sp += push ? JADE_COL_STRIDE : 0u;
   // ---- pop (a lane pushes or pops, never both)
-  const bool do_pop = need_pop && sp > 0;
-  const uint32_t sp1 = sp - 1u;
-  uint32_t top = lds_get_w(stk, (do_pop && sp1 < JADE_LDS_STACK) ? sp1 : (uint32_t)LW_DUMMY);
-  asm volatile("" : "+v"(top));  // keeps the LDS read a ds_read (see stack_pop)
-  if (do_pop && sp1 >= JADE_LDS_STACK) top = stk.spill[(size_t)(sp1 - JADE_LDS_STACK) * stk.stride_spill];  // rare
-  sp -= do_pop ? 1u : 0u;
+  const bool do_pop = need_pop && sp != stk.col;
+  const uint32_t sp1 = sp - JADE_COL_STRIDE;
+  uint32_t top = lds_ld((do_pop && sp1 < lds_end) ? sp1 : dummy);
+  asm volatile("" : "+v"(top));  // keeps it a ds_read: "LDS, or global for some lanes" would become one FLAT load through a selected generic pointer
+  if (do_pop && sp1 >= lds_end) top = stk.spill[(size_t)((sp1 - lds_end) / JADE_COL_STRIDE) * stk.stride_spill];  // rare
+  r.sp = do_pop ? sp1 : sp;
   r.cur = need_pop ? (do_pop ? top : JADE_REF_NONE) : next;
-  r.sp = sp;
 }
 
-#if !JADE_PAIR
-// One triangle of the leaf at the head of the FIFO for a lane with ray_can_test.  tcnt: this lane's count of tests.
-static __device__ __forceinline__ void ray_step_tri_s(RayState& r, const DevScene& S, const LdsStack& stk, uint32_t& tcnt) {
-  const uint32_t off = r.leaf & 0x7ffffff0u;
-  const char* t0 = reinterpret_cast<const char*>(S.tverts) + off;
-  const float4 q0 = *reinterpret_cast<const float4*>(t0);
-  const float2 q1 = *reinterpret_cast<const float2*>(t0 + 16);
-  const V3ld q3 = *reinterpret_cast<const V3ld*>(t0 + 24);
-  const jvec3 p3 = jv(q3.x, q3.y, q3.z);
-  uint32_t leaf = r.leaf + 47u;  // next record, count - 1
-  const bool tested = off != (r.skipx & 0x7fffffffu);  // the source triangle is skipped by index, PathTrace.cu:782
-  tcnt += tested ? 1u : 0u;
-  float dist;
-  jvec3 P;
-  if (tested && tri_test(q0, q1, p3, r.od, &dist, &P) && dist < lds_getf(stk, LW_BEST_DIST)) {  // a hit: rare
-    lds_putf(stk, LW_BEST_DIST, dist);
-    lds_put(stk, LW_BEST_INDEX, off);
-    lds_putf(stk, LW_PX, P.x);
-    lds_putf(stk, LW_PY, P.y);
-    lds_putf(stk, LW_PZ, P.z);
-  }
-  // leaf finished: the next one from the FIFO, if any
-  const bool fin = (leaf & 15u) == 0;
-  const bool has = r.fw != r.fr;
-  const uint32_t nxt = lds_get_w(stk, (uint32_t)LW_FIFO + (r.fr & (JADE_LDS_FIFO - 1)));
-  r.leaf = fin ? (has ? nxt : 0u) : leaf;
-  r.fr += (fin && has) ? 1u : 0u;
-}
-
-#endif  // !JADE_PAIR
-
-#if JADE_PAIR
 // ---------------------------------------------------------------------------------------------------------------
 // Two triangles per test.  The triangle test is half of k_trace's instructions on the rays that matter (jade paths:
-// 40 tests per ray), and tri_test above packs only HALF of it: the statements for p1 and p2 share instructions, those
-// for p3 - and the third triple product - run alone.  Two consecutive triangles of a leaf have no such remainder: every
-// statement of hitTriangle (PathTrace.cu:705-754) runs once for triangle A in lane .x and for triangle B in lane .y of a
+// 40 tests per ray).  Two consecutive triangles of a leaf share every instruction: each statement of hitTriangle
+// (PathTrace.cu:705-754, normalize(dir) hoisted) runs once for triangle A in lane .x and for triangle B in lane .y of a
 // packed instruction (IEEE per component: the values are those of the scalar statements).  The vertex data is laid out
 // for it (jade_scene_create): one 80-B record per pair,
 //   {A.p1x B.p1x A.p1y B.p1y} {A.p1z B.p1z A.p2x B.p2x} {A.p2y B.p2y A.p2z B.p2z} {A.p3x B.p3x A.p3y B.p3y}
 //   {A.p3z B.p3z indexA flags}          flags bit 0: B is a triangle (an odd leaf's last record repeats A and clears it),
-// and a leaf reference is LEAF | 5 * first_pair << 4 | pairs: bits 4-30 are still the byte offset of the next record.
-// A is resolved before B (hitArray's index order, strict "<"), the source triangle is skipped by index in either lane.
+// and a leaf reference is LEAF | 5 * first_pair << 4 | pairs: bits 4-30 are the byte offset of the next record.
+// A is resolved before B (hitArray's index order, :776-792, strict "<"), the source triangle is skipped by index in
+// either lane (:782).
 // ---------------------------------------------------------------------------------------------------------------
-static __device__ __forceinline__ f2 f2sel(f2 v, int hi) { return hi ? f2{v.y, v.y} : f2{v.x, v.x}; }
-
 // the part of hitTriangle that runs once the projected origin is inside the projected triangle (:732-747)
 static __device__ __forceinline__ bool tri_hit(jvec3 p1, jvec3 p2, jvec3 p3, jvec3 sa, jvec3 sb, jvec3 sc, jvec3 o, jvec3 dn, float* dist_out,
                                                jvec3* point_out) {
@@ -595,6 +364,7 @@ static __device__ __forceinline__ bool tri_hit(jvec3 p1, jvec3 p2, jvec3 p3, jve
   return distance > 0;
 }
 
+// One pair of the leaf at the head of the FIFO for a lane with ray_can_test.  tcnt: this lane's count of tests.
 static __device__ __forceinline__ void ray_step_tri_s(RayState& r, const DevScene& S, const LdsStack& stk, uint32_t& tcnt) {
   const uint32_t off = r.leaf & 0x7ffffff0u;
   const float4* t0 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.tverts) + off);
@@ -660,8 +430,7 @@ static __device__ __forceinline__ void ray_step_tri_s(RayState& r, const DevScen
   // leaf finished: the next one from the FIFO, if any
   const bool fin = (leaf & 15u) == 0;
   const bool has = r.fw != r.fr;
-  const uint32_t nxt = lds_get_w(stk, (uint32_t)LW_FIFO + (r.fr & (JADE_LDS_FIFO - 1)));
+  const uint32_t nxt = lds_ld((stk.col + LW_FIFO * JADE_COL_STRIDE) | (r.fr & JADE_FIFO_MASK));
   r.leaf = fin ? (has ? nxt : 0u) : leaf;
-  r.fr += (fin && has) ? 1u : 0u;
+  r.fr += (fin && has) ? JADE_COL_STRIDE : 0u;
 }
-#endif  // JADE_PAIR
