@@ -494,7 +494,8 @@ __global__ __launch_bounds__(JADE_LEAN_BLOCK) void k_shade_lean(DevScene S, Path
 #endif
 __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(DevScene S, PathState P, const uint32_t* queue, QueueCtl* qc,
                                                            uint32_t* spill, DevCounters* ctr, uint32_t chunk) {
-  __shared__ __attribute__((aligned(JADE_COLS_ALIGN))) uint32_t lds_cols[JADE_CTX_WORDS * JADE_TRACE_BLOCK];
+  __shared__ uint32_t lds_cols[TW_END * JADE_TRACE_BLOCK];
+  __shared__ __attribute__((aligned(8))) uint32_t lds_wq[JADE_TRACE_BLOCK / 64][2 * JADE_WQ];  // a wave's queue of leaves to test (jade_trace.h)
   const int lane = threadIdx.x & 63;
   const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
   LdsStack stk;
@@ -531,26 +532,44 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
   // wave-local chunk of the queue: [lbase, lend) (wave-uniform)
   uint32_t lbase = 0, lend = 0;
   bool queue_empty = false;
-  bool active = false;
-  bool wb = false;    // this lane's ray has finished and its result is still in the LDS column
-  uint32_t my_e = 0;  // this lane's queue entry: slot * npix + record
-  RayState r;
+  bool active = false;  // this lane walks a ray, or waits for the last of its leaves to be tested
+  bool wb = false;      // this lane's ray has ended and its result is still in the LDS column
+  uint32_t my_e = 0;    // this lane's queue entry: slot * npix + record
+  WalkState r;
+  r.od.a = r.od.b = r.od.c = f2{0.0f, 0.0f};
+  r.skipx = 0;
+  r.cur = JADE_REF_NONE;
+  r.sp = stk.col;
+  r.pushed = 0;
+  // the wave's ring of leaves to test: q_count items from q_head on (wave-uniform), and the item this lane is testing
+  const uint32_t wq = lds_addr_of(&lds_wq[threadIdx.x >> 6][0]);
+  uint32_t q_head = 0, q_count = 0;
+  uint32_t item_leaf = 0, item_meta = 0;
+  const uint32_t lane_below_lo = lane < 32 ? (1u << lane) - 1u : 0xffffffffu, lane_below_hi = lane < 32 ? 0u : (1u << (lane - 32)) - 1u;
+  auto rank_in = [&](unsigned long long m) -> uint32_t {  // lanes of m below this one
+    return (uint32_t)__popc((uint32_t)m & lane_below_lo) + (uint32_t)__popc((uint32_t)(m >> 32) & lane_below_hi);
+  };
   for (;;) {
-    // ---- once enough lanes are idle (or all are): write their results back and refill them.
-    // Both are done for >= JADE_REFILL_MIN lanes at a time, not whenever a single ray ends:
-    // the kernel is bound by VALU issue (PMC: the VALU of every SIMD busy 92-94 % of the time) and a
-    // block that runs for one lane costs as much as for 64.
+    // ---- a ray has ended when its walk has and all the leaves it pushed have been finished
+    if (active && r.cur == JADE_REF_NONE && lds_ld_v(stk.col + TW_FINISHED * JADE_COL_STRIDE) == r.pushed) {
+      active = false;
+      wb = true;
+    }
+    // ---- once enough lanes are idle (or all are): write their results back and refill them.  Both are done for >=
+    // JADE_REFILL_MIN lanes at a time, not whenever a single ray ends: the kernel is bound by VALU issue and a block that
+    // runs for one lane costs as much as for 64.
     const unsigned long long idle = __ballot(!active);
     const int n_idle = __popcll(idle);
     if (n_idle >= JADE_REFILL_MIN) {
       if (wb) {
         // ray records stream through once per pass: non-temporal, so that they do not push the BVH out of the XCD's
         // 4 MB L2 (C3's node + vertex records are 4.1 MB; PMC: 124 of the 172 HBM bytes per ray were BVH lines re-fetched)
-        const int32_t best = ray_best_index(stk);
+        float dist;
+        jvec3 hp;
+        const int32_t best = walk_result(stk, S, r.od, &dist, &hp);
         NT_ST(&P.hit[my_e], best);
-        if (P.hdist) P.hdist[my_e] = lds_getf(stk, LW_BEST_DIST);  // wave-uniform: only jade_trace_rays asks for it
+        if (P.hdist) P.hdist[my_e] = dist;  // wave-uniform: only jade_trace_rays asks for it
         if (best >= 0) {  // the hit point of a miss is never read
-          const jvec3 hp = ray_hit_point(stk);
           float* hb = P.hpt + my_e;
           NT_ST(&hb[0], hp.x);
           NT_ST(&hb[plane], hp.y);
@@ -573,7 +592,7 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
         }
         const uint32_t avail = lend - lbase;
         const uint32_t take = (uint32_t)n_idle < avail ? (uint32_t)n_idle : avail;
-        const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+        const uint32_t rank = rank_in(idle);
         if (!active && rank < take) {
           my_e = NT_LD(&queue[lbase + rank]);
           const uint32_t k = my_e / (uint32_t)npix, p = my_e - k * (uint32_t)npix;
@@ -582,57 +601,87 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
                                                    : jv(NT_LD(&P.org[p]), NT_LD(&P.org[npix + p]), NT_LD(&P.org[2 * npix + p]));
           const float* db = P.dir + my_e;
           const jvec3 d = jv(NT_LD(&db[0]), NT_LD(&db[plane]), NT_LD(&db[2 * plane]));
-          ray_begin(r, stk, S, o, d, skip);
+          walk_begin(r, stk, S, o, d, skip);
           active = true;
         }
         V += take;  // the root record of every ray started
         lbase += take;
       }
     }
-    if (n_idle == 64 && queue_empty) break;  // nothing in flight, nothing left to claim (results are written: 64 >= REFILL_MIN)
-    // ---- one kind of work per iteration, for every lane that has some of it: node walk or
-    // triangle tests (jade_trace.h).  The kind that advances more lanes per instruction issued runs.
-    {
-      const bool cw = active && ray_can_walk(r), ct = active && ray_can_test(r);
-      const int nw = __popcll(__ballot(cw)), nt = __popcll(__ballot(ct));
-      if (JADE_COST_TRI * nw >= JADE_COST_NODE * nt) {
-        // the general form of the node step (NaN-faithful slabs, missing children) is needed by few waves: decided per WAVE
-        // (a scalar branch), not per lane - it is right for every ray
-        if (S.general_walk || __ballot(active && (int32_t)r.skipx < 0) != 0ull) {
+    if (n_idle == 64 && queue_empty) break;  // nothing in flight (so no leaf is waiting either), nothing left to claim
+    // ---- one kind of work per iteration: the walk, for the lanes whose ray still walks, or triangle tests, for as many
+    // lanes as there are leaves waiting.  The kind that advances more lanes per instruction issued runs; the walk needs
+    // room for the 64 leaves one unit of it can push.
+    const int nw = __popcll(__ballot(active && r.cur != JADE_REF_NONE));
+    const uint32_t n_items = q_count + (uint32_t)__popcll(__ballot(item_leaf != 0));
+    const uint32_t nt = n_items < 64u ? n_items : 64u;
+    if (q_count <= JADE_WQ - 64 && nw > 0 && JADE_COST_TRI * (uint32_t)nw >= JADE_COST_NODE * nt) {
+      const bool general = S.general_walk || __ballot(active && (int32_t)r.skipx < 0) != 0ull;  // per WAVE (jade_trace.h)
 #pragma nounroll
-          for (int rep = 0; rep < JADE_STEPS_PER_PICK; ++rep)
-            if (active && ray_can_walk(r)) ray_step_node_s<true>(r, S, stk, vcnt);
-        } else {
-#pragma nounroll
-          for (int rep = 0; rep < JADE_STEPS_PER_PICK; ++rep) {
+      for (int rep = 0; rep < JADE_STEPS_PER_PICK; ++rep) {
+        if (q_count > JADE_WQ - 64) break;
+        const bool go = active && r.cur != JADE_REF_NONE;
 #if JADE_TRACE_PROFILE == 1
-            prof_units += 1;
-            prof_lanes += (uint32_t)__popcll(__ballot(active && ray_can_walk(r)));
+        prof_units += 1;
+        prof_lanes += (uint32_t)__popcll(__ballot(go));
 #endif
-            if (active && ray_can_walk(r)) ray_step_node_s<false>(r, S, stk, vcnt);
-          }
+        uint32_t leafv = 0;
+        if (general) {
+          if (go) leafv = walk_step<true>(r, S, stk, vcnt);
+        } else {
+          if (go) leafv = walk_step<false>(r, S, stk, vcnt);
         }
-      } else {
-#pragma nounroll
-        for (int rep = 0; rep < JADE_STEPS_PER_PICK; ++rep) {
-          const bool go = active && ray_can_test(r);
-#if JADE_TRACE_PROFILE == 2
-          prof_units += 1;
-          prof_lanes += (uint32_t)__popcll(__ballot(go));
-#endif
-          if (go) ray_step_tri_s(r, S, stk, tcnt);
+        // the leaves met by this unit, in lane order (any order would do: a leaf's place among its ray's leaves is its
+        // sequence number)
+        const unsigned long long m = __ballot(leafv != 0);
+        if (m != 0ull) {
+          if (leafv != 0) {
+            const uint32_t slot = (q_head + q_count + rank_in(m)) & (JADE_WQ - 1u);
+            lds_st64(wq + slot * 8u, leafv, (uint32_t)lane | (r.pushed << 6));
+            r.pushed += 1u;
+          }
+          q_count += (uint32_t)__popcll(m);
         }
       }
-#if JADE_TRACE_PROFILE == 3
-      prof_units += 1;
-      prof_lanes += (uint32_t)__popcll(__ballot(active));
+    } else {
+#pragma nounroll
+      for (int rep = 0; rep < JADE_STEPS_PER_PICK; ++rep) {
+        // lanes without an item take the next ones from the ring
+        const unsigned long long need = __ballot(item_leaf == 0);
+        if (q_count != 0 && need != 0ull) {
+          const uint32_t rk = rank_in(need);
+          if (item_leaf == 0 && rk < q_count) {
+            lds_ld64(wq + ((q_head + rk) & (JADE_WQ - 1u)) * 8u, item_leaf, item_meta);
+          }
+          const uint32_t want = (uint32_t)__popcll(need);
+          const uint32_t npop = want < q_count ? want : q_count;
+          q_head = (q_head + npop) & (JADE_WQ - 1u);
+          q_count -= npop;
+        }
+        const bool go = item_leaf != 0;
+        if (__ballot(go) == 0ull) break;
+#if JADE_TRACE_PROFILE == 2
+        prof_units += 1;
+        prof_lanes += (uint32_t)__popcll(__ballot(go));
 #endif
+        // the ray an item belongs to: seven registers of the lane that walks it (every lane executes the reads: ds_bpermute
+        // returns 0 for a source lane that is masked off)
+        const int owner = (int)(item_meta & 63u);
+        RayOD od;
+        od.a.x = __shfl(r.od.a.x, owner, 64);
+        od.a.y = __shfl(r.od.a.y, owner, 64);
+        od.b.x = __shfl(r.od.b.x, owner, 64);
+        od.b.y = __shfl(r.od.b.y, owner, 64);
+        od.c.x = __shfl(r.od.c.x, owner, 64);
+        od.c.y = __shfl(r.od.c.y, owner, 64);
+        const uint32_t skip = (uint32_t)__shfl((int)r.skipx, owner, 64) & 0x7fffffffu;
+        if (go) test_step(item_leaf, item_meta, od, skip, S, stk, lane, tcnt);
+      }
     }
-    const bool fin = active && ray_done(r);
-    if (fin) {
-      active = false;
-      wb = true;
-    }
+#if JADE_TRACE_PROFILE == 3
+    prof_units += 1;
+    prof_lanes += (uint32_t)__popcll(__ballot(active));
+#endif
   }
   V += (uint32_t)wave_sum_u32(vcnt);  // (valid in lane 0, the only lane that uses it)
   T += (uint32_t)wave_sum_u32(tcnt);

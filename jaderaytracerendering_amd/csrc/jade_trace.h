@@ -62,6 +62,15 @@ typedef __attribute__((address_space(3))) uint32_t jade_lds_u32;
 static __device__ __forceinline__ uint32_t lds_addr_of(const uint32_t* p) { return (uint32_t)(__SIZE_TYPE__)(jade_lds_u32*)p; }
 static __device__ __forceinline__ void lds_st(uint32_t addr, uint32_t v) { *(jade_lds_u32*)(__SIZE_TYPE__)addr = v; }
 static __device__ __forceinline__ uint32_t lds_ld(uint32_t addr) { return *(jade_lds_u32*)(__SIZE_TYPE__)addr; }
+typedef __attribute__((address_space(3))) unsigned long long jade_lds_u64;
+static __device__ __forceinline__ void lds_st64(uint32_t addr, uint32_t lo, uint32_t hi) {
+  *(jade_lds_u64*)(__SIZE_TYPE__)addr = (unsigned long long)lo | ((unsigned long long)hi << 32);
+}
+static __device__ __forceinline__ void lds_ld64(uint32_t addr, uint32_t& lo, uint32_t& hi) {
+  const unsigned long long v = *(jade_lds_u64*)(__SIZE_TYPE__)addr;
+  lo = (uint32_t)v;
+  hi = (uint32_t)(v >> 32);
+}
 
 struct LdsStack {
   uint32_t* lds;       // this lane's column (word k at lds[k * JADE_TRACE_BLOCK])
@@ -232,9 +241,13 @@ static __device__ __forceinline__ jvec3 ray_hit_point(const LdsStack& stk) {
 // GENERAL = false leaves out what almost no wave needs (decided per wave, a scalar branch in the caller): the
 // NaN-faithful slab reduction (a ray with a non-finite 1/d or origin) and children that do not exist (the reference's
 // "child 0"; jade_scene_create tells whether the tree has any).
-template <bool GENERAL>
-static __device__ __forceinline__ void ray_step_node_s(RayState& r, const DevScene& S, const LdsStack& stk, uint32_t& vcnt) {
-  const uint32_t cur = r.cur;
+// The core shared by the two forms of the walk (a FIFO of leaf cursors per lane: k_light; one queue of leaves per wave:
+// k_trace).  W_INV / W_DUMMY: where the column keeps 1/d and the dummy word.  room: a leaf met now can be taken.  Returns
+// the leaf met (0 = none); cur and sp advance.
+template <bool GENERAL, int W_INV, int W_DUMMY>
+static __device__ __forceinline__ uint32_t node_core(uint32_t& cur_io, uint32_t& sp_io, const RayOD& od, const DevScene& S, const LdsStack& stk, bool room,
+                                                     uint32_t& vcnt) {
+  const uint32_t cur = cur_io;
   const bool is_leaf = (int32_t)cur < 0;
   const uint32_t node = is_leaf ? 0u : cur;  // such a lane reads record 0 and ignores it
   float4 a, b, c;
@@ -278,18 +291,18 @@ static __device__ __forceinline__ void ray_step_node_s(RayState& r, const DevSce
     rf = *reinterpret_cast<const uint2*>(nd + 3);
   }
 #endif
-  const jvec3 inv = jv(lds_getf(stk, LW_INVX), lds_getf(stk, LW_INVY), lds_getf(stk, LW_INVZ));
+  const jvec3 inv = jv(lds_getf(stk, W_INV), lds_getf(stk, W_INV + 1), lds_getf(stk, W_INV + 2));
   float d1, d2;
 #if JADE_ABLATE_SLAB
   {
-    RayOD o2 = r.od;
+    RayOD o2 = od;
     o2.a.x += 1e-30f;
     float e1, e2;
     slab2(o2, inv, a, b, c, GENERAL, &e1, &e2);
     asm volatile("" ::"v"(e1 + e2));
   }
 #endif
-  slab2(r.od, inv, a, b, c, GENERAL, &d1, &d2);
+  slab2(od, inv, a, b, c, GENERAL, &d1, &d2);
   bool in1, in2;
   if (GENERAL) {
     const bool c1 = !is_leaf && rf.x != JADE_REF_NONE, c2 = !is_leaf && rf.y != JADE_REF_NONE;  // a missing child is neither counted nor entered
@@ -305,26 +318,17 @@ static __device__ __forceinline__ void ray_step_node_s(RayState& r, const DevSce
   const bool first = d1 < d2;  // near child first, PathTrace.cu:835-848
   const uint32_t near = both ? (first ? rf.x : rf.y) : (in1 ? rf.x : rf.y);
   const uint32_t far = first ? rf.y : rf.x;
-  const bool near_leaf_ok = any && (int32_t)near < 0 && leaf_room(r);  // the near leaf is met now
+  const bool near_leaf_ok = any && (int32_t)near < 0 && room;  // the near leaf is met now
   // both, near leaf met: the far child is next, nothing to push.  both otherwise: push far, go near.  one: go there (a
   // leaf that is met ends the branch: pop).  none: pop.
   const uint32_t leafv = is_leaf ? cur : (near_leaf_ok ? near : 0u);
   const bool push = both && !near_leaf_ok;
   const uint32_t next = both ? (near_leaf_ok ? far : near) : near;
   const bool need_pop = is_leaf || !any || (!both && near_leaf_ok);
-  const uint32_t dummy = stk.col + LW_DUMMY * JADE_COL_STRIDE;
-  // ---- the leaf met goes to the leaf cursor, or behind it into the FIFO
-  {
-    const bool lq = (leafv & 15u) != 0;  // (an empty leaf cannot happen for a valid BVH)
-    const bool to_fifo = lq && r.leaf != 0;
-    const uint32_t slot = (stk.col + LW_FIFO * JADE_COL_STRIDE) | (r.fw & JADE_FIFO_MASK);
-    lds_st(to_fifo ? slot : dummy, leafv);
-    r.leaf = (lq && r.leaf == 0) ? leafv : r.leaf;
-    r.fw += to_fifo ? JADE_COL_STRIDE : 0u;
-  }
+  const uint32_t dummy = stk.col + W_DUMMY * JADE_COL_STRIDE;
   // ---- push the far child
   const uint32_t lds_end = stk.col + JADE_LDS_STACK * JADE_COL_STRIDE;  // address of the first level that is not in LDS
-  uint32_t sp = r.sp;
+  uint32_t sp = sp_io;
   lds_st((push && sp < lds_end) ? sp : dummy, far);
   if (push && sp >= lds_end) stk.spill[(size_t)((sp - lds_end) / JADE_COL_STRIDE) * stk.stride_spill] = far;  // rare
   sp += push ? JADE_COL_STRIDE : 0u;
@@ -334,8 +338,22 @@ static __device__ __forceinline__ void ray_step_node_s(RayState& r, const DevSce
   uint32_t top = lds_ld((do_pop && sp1 < lds_end) ? sp1 : dummy);
   asm volatile("" : "+v"(top));  // keeps it a ds_read: "LDS, or global for some lanes" would become one FLAT load through a selected generic pointer
   if (do_pop && sp1 >= lds_end) top = stk.spill[(size_t)((sp1 - lds_end) / JADE_COL_STRIDE) * stk.stride_spill];  // rare
-  r.sp = do_pop ? sp1 : sp;
-  r.cur = need_pop ? (do_pop ? top : JADE_REF_NONE) : next;
+  sp_io = do_pop ? sp1 : sp;
+  cur_io = need_pop ? (do_pop ? top : JADE_REF_NONE) : next;
+  return leafv;
+}
+
+// The walk with a FIFO of leaf cursors per lane (k_light): one unit for a lane with ray_can_walk.
+template <bool GENERAL>
+static __device__ __forceinline__ void ray_step_node_s(RayState& r, const DevScene& S, const LdsStack& stk, uint32_t& vcnt) {
+  const uint32_t leafv = node_core<GENERAL, LW_INVX, LW_DUMMY>(r.cur, r.sp, r.od, S, stk, leaf_room(r), vcnt);
+  // the leaf met goes to the leaf cursor, or behind it into the FIFO
+  const bool lq = (leafv & 15u) != 0;  // (an empty leaf cannot happen for a valid BVH)
+  const bool to_fifo = lq && r.leaf != 0;
+  const uint32_t slot = (stk.col + LW_FIFO * JADE_COL_STRIDE) | (r.fw & JADE_FIFO_MASK);
+  lds_st(to_fifo ? slot : stk.col + LW_DUMMY * JADE_COL_STRIDE, leafv);
+  r.leaf = (lq && r.leaf == 0) ? leafv : r.leaf;
+  r.fw += to_fifo ? JADE_COL_STRIDE : 0u;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -364,16 +382,14 @@ static __device__ __forceinline__ bool tri_hit(jvec3 p1, jvec3 p2, jvec3 p3, jve
   return distance > 0;
 }
 
-// One pair of the leaf at the head of the FIFO for a lane with ray_can_test.  tcnt: this lane's count of tests.
-static __device__ __forceinline__ void ray_step_tri_s(RayState& r, const DevScene& S, const LdsStack& stk, uint32_t& tcnt) {
-  const uint32_t off = r.leaf & 0x7ffffff0u;
-  const float4* t0 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.tverts) + off);
+// The packed test of one pair record for one ray: is the projected origin inside the projected triangle A / B (:711-731)?
+// skip: the ray's source triangle.  tcnt: this lane's count of tests.
+static __device__ __forceinline__ void pair_core(const RayOD& od, uint32_t skip, const float4* t0, uint32_t& tcnt, bool& in_a_out, bool& in_b_out,
+                                                 uint32_t& idx_a_out) {
   const float4 q0 = t0[0], q1 = t0[1], q2 = t0[2], q3 = t0[3], q4 = t0[4];
-  const uint32_t leaf = r.leaf + 79u;  // next pair record (5 x 16 B), one pair fewer
-  const uint32_t idx_a = jade_f2u(q4.z), skip = r.skipx & 0x7fffffffu;
+  const uint32_t idx_a = jade_f2u(q4.z);
   const bool test_a = idx_a != skip, test_b = (jade_f2u(q4.w) & 1u) != 0 && idx_a + 1u != skip;
   tcnt += (test_a ? 1u : 0u) + (test_b ? 1u : 0u);
-  const RayOD& od = r.od;
   // lane .x: triangle A, lane .y: triangle B
   const f2 p1x = {q0.x, q0.y}, p1y = {q0.z, q0.w}, p1z = {q1.x, q1.y};
   const f2 p2x = {q1.z, q1.w}, p2y = {q2.x, q2.y}, p2z = {q2.z, q2.w};
@@ -401,23 +417,39 @@ static __device__ __forceinline__ void ray_step_tri_s(RayState& r, const DevScen
   pcpa = f2fma(OD_DZ(od), f2fma(pcx, pay, -(pcy * pax)), pcpa);
   const bool in_a = test_a && ((papb.x > 0 && pbpc.x > 0 && pcpa.x > 0) || (papb.x < 0 && pbpc.x < 0 && pcpa.x < 0));
   const bool in_b = test_b && ((papb.y > 0 && pbpc.y > 0 && pcpa.y > 0) || (papb.y < 0 && pbpc.y < 0 && pcpa.y < 0));
-  if (in_a || in_b) {
-    // Rare (one test in ten, 2 % of the kernel's time): the barycentric solve, the distance and the best hit so far, A before
-    // B (index order, strict "<").  Nothing of the packed test is kept alive for it - the record is read again (it is in L1)
-    // and the triangle's three projections are recomputed with the same statements - because 36 registers held across the
-    // test for this block cost the kernel a wave per SIMD.
-    const jvec3 o = od_o(od), dn = od_dn(od);
+  in_a_out = in_a;
+  in_b_out = in_b;
+  idx_a_out = idx_a;
+}
+// Triangle k (0 = A, 1 = B) of a pair record the origin projects into: the barycentric solve and the distance (:732-747).
+// Rare (one test in ten, 2 % of the kernel's time).  Nothing of the packed test is kept alive for it - the record is read
+// again (it is in L1) and the triangle's three projections are recomputed with the same statements - because 36 registers
+// held across the test for this block cost the kernel a wave per SIMD.
+static __device__ __forceinline__ bool pair_hit(const float4* t0, int k, const RayOD& od, float* dist, jvec3* P) {
+  const jvec3 o = od_o(od), dn = od_dn(od);
+  const float* f = reinterpret_cast<const float*>(t0) + k;  // lane k of every pair
+  const jvec3 p1 = jv(f[0], f[2], f[4]), p2 = jv(f[6], f[8], f[10]), p3 = jv(f[12], f[14], f[16]);
+  const jvec3 sa = jv_sub(p1, jv_scale(dn, jv_dot(dn, jv_sub(p1, o))));
+  const jvec3 sb = jv_sub(p2, jv_scale(dn, jv_dot(dn, jv_sub(p2, o))));
+  const jvec3 sc = jv_sub(p3, jv_scale(dn, jv_dot(dn, jv_sub(p3, o))));
+  return tri_hit(p1, p2, p3, sa, sb, sc, o, dn, dist, P);
+}
+
+// One pair of the leaf at the head of the FIFO for a lane with ray_can_test (k_light).
+static __device__ __forceinline__ void ray_step_tri_s(RayState& r, const DevScene& S, const LdsStack& stk, uint32_t& tcnt) {
+  const uint32_t off = r.leaf & 0x7ffffff0u;
+  const float4* t0 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.tverts) + off);
+  const uint32_t leaf = r.leaf + 79u;  // next pair record (5 x 16 B), one pair fewer
+  bool in_a, in_b;
+  uint32_t idx_a;
+  pair_core(r.od, r.skipx & 0x7fffffffu, t0, tcnt, in_a, in_b, idx_a);
+  if (in_a || in_b) {  // A before B (index order, strict "<")
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       if (k == 0 ? in_a : in_b) {
-        const float* f = reinterpret_cast<const float*>(t0) + k;  // lane k of every pair
-        const jvec3 p1 = jv(f[0], f[2], f[4]), p2 = jv(f[6], f[8], f[10]), p3 = jv(f[12], f[14], f[16]);
-        const jvec3 sa = jv_sub(p1, jv_scale(dn, jv_dot(dn, jv_sub(p1, o))));
-        const jvec3 sb = jv_sub(p2, jv_scale(dn, jv_dot(dn, jv_sub(p2, o))));
-        const jvec3 sc = jv_sub(p3, jv_scale(dn, jv_dot(dn, jv_sub(p3, o))));
         float dist;
         jvec3 P;
-        if (tri_hit(p1, p2, p3, sa, sb, sc, o, dn, &dist, &P) && dist < lds_getf(stk, LW_BEST_DIST)) {
+        if (pair_hit(t0, k, r.od, &dist, &P) && dist < lds_getf(stk, LW_BEST_DIST)) {
           lds_putf(stk, LW_BEST_DIST, dist);
           lds_put(stk, LW_BEST_INDEX, idx_a + (uint32_t)k);
           lds_putf(stk, LW_PX, P.x);
@@ -433,4 +465,137 @@ static __device__ __forceinline__ void ray_step_tri_s(RayState& r, const DevScen
   const uint32_t nxt = lds_ld((stk.col + LW_FIFO * JADE_COL_STRIDE) | (r.fr & JADE_FIFO_MASK));
   r.leaf = fin ? (has ? nxt : 0u) : leaf;
   r.fr += (fin && has) ? JADE_COL_STRIDE : 0u;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_trace's form: the leaves a wave's rays meet go into ONE queue per wave, and ANY lane tests them.
+//
+// With a FIFO per lane, a lane tests the triangles of its own ray, so an iteration of triangle tests runs for the lanes
+// whose own ray has a leaf waiting and an iteration of the walk for the lanes whose own ray still walks (and has room):
+// on the incoherent rays of the jade paths 29 of 64 lanes worked in an average VALU instruction, and the kernel is
+// bound by the number of instructions it issues.  But a triangle test needs nothing of the lane it runs on: the ray's
+// origin, direction and skip index are seven registers of the lane that walks it (read with ds_bpermute), and its
+// result is a candidate for that lane's best hit.  So:
+//   * the walk pushes every leaf it meets as an item {leaf cursor, owner lane | sequence number} onto the wave's ring
+//     in LDS (one prefix count per unit, no atomics: a wave runs in lock step);
+//   * a test iteration hands the queued items to the lanes in order - ALL lanes, also the ones that hold no ray or whose
+//     ray is through with its walk - one pair record per lane and unit, a leaf stays with its lane until it is finished;
+//   * hitArray's order (:776-792: leaves as the walk meets them, triangles by index, strict "<" so that the first of
+//     two equal distances wins) does not depend on WHEN a leaf is tested: a candidate replaces the owner's best hit if
+//     its distance is smaller, or equal with a smaller sequence number (within a leaf one lane tests in index order).
+//     Two lanes with candidates for the same ray in the same instruction take turns through a lock word in the owner's
+//     column;
+//   * a ray has ended when its walk has and as many of its leaves have been finished (an LDS counter in its column,
+//     ds_add by whoever finishes one) as it pushed.  Its hit point is computed then, once, from the winning triangle
+//     (the same statements as in the test: same bits), instead of travelling with every candidate.
+// A lane's column: the stack, 1/d, the best hit {distance, sequence, record | A/B}, the finished-leaf counter, a dummy.
+// ---------------------------------------------------------------------------------------------------------------
+enum { TW_INVX = JADE_LDS_STACK, TW_INVY, TW_INVZ, TW_BEST_DIST, TW_BEST_SEQ, TW_BEST_REF, TW_FINISHED, TW_DUMMY, TW_END };
+#ifndef JADE_WQ
+#define JADE_WQ 128 /* items a wave's ring holds (a power of two, >= 128: a walk unit may push 64) */
+#endif
+static_assert((JADE_WQ & (JADE_WQ - 1)) == 0 && JADE_WQ >= 128, "JADE_WQ");
+
+struct WalkState {
+  RayOD od;         // origin and normalize(d)
+  uint32_t skipx;   // as in RayState
+  uint32_t cur;     // internal-node ref, a leaf ref (a far child off the stack), or JADE_REF_NONE = walk finished
+  uint32_t sp;      // LDS byte address of the next free stack level
+  uint32_t pushed;  // leaves met so far = the next leaf's sequence number
+};
+static __device__ __forceinline__ void lds_st_v(uint32_t addr, uint32_t v) { *(volatile jade_lds_u32*)(__SIZE_TYPE__)addr = v; }
+static __device__ __forceinline__ uint32_t lds_ld_v(uint32_t addr) { return *(volatile jade_lds_u32*)(__SIZE_TYPE__)addr; }
+
+static __device__ __forceinline__ void walk_begin(WalkState& r, const LdsStack& stk, const DevScene& S, jvec3 o, jvec3 d, int32_t skip) {
+  const jvec3 inv = jv(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  const jvec3 dn = jv_normalize(d);
+  r.od.a = f2{o.x, o.y};
+  r.od.b = f2{o.z, dn.x};
+  r.od.c = f2{dn.y, dn.z};
+  const bool exact = !(finite_f(inv.x) && finite_f(inv.y) && finite_f(inv.z)) || !finite_f(o.x) || !finite_f(o.y) || !finite_f(o.z);
+  r.skipx = (skip < 0 ? 0x7fffffffu : (uint32_t)skip) | (exact ? 0x80000000u : 0u);
+  r.sp = stk.col;
+  r.pushed = 0;
+  r.cur = S.root_ref;
+  lds_putf(stk, TW_INVX, inv.x);
+  lds_putf(stk, TW_INVY, inv.y);
+  lds_putf(stk, TW_INVZ, inv.z);
+  lds_putf(stk, TW_BEST_DIST, JADE_INF_F);
+  lds_put(stk, TW_BEST_SEQ, 0xffffffffu);
+  lds_put(stk, TW_BEST_REF, 0xffffffffu);
+  lds_st_v(stk.col + TW_FINISHED * JADE_COL_STRIDE, 0u);
+}
+// One unit of the walk for a lane whose walk has not ended.  Returns the leaf met (0 = none): the caller queues it.
+template <bool GENERAL>
+static __device__ __forceinline__ uint32_t walk_step(WalkState& r, const DevScene& S, const LdsStack& stk, uint32_t& vcnt) {
+  const uint32_t leafv = node_core<GENERAL, TW_INVX, TW_DUMMY>(r.cur, r.sp, r.od, S, stk, true, vcnt);
+  return (leafv & 15u) != 0 ? leafv : 0u;  // (an empty leaf cannot happen for a valid BVH)
+}
+
+// One pair record of the item a lane holds: item_leaf = the leaf cursor (0 afterwards if the leaf is finished), meta =
+// owner lane | sequence << 6, od / skip = the owner's ray (the caller's ds_bpermute), lane = this lane.
+static __device__ __forceinline__ void test_step(uint32_t& item_leaf, uint32_t meta, const RayOD& od, uint32_t skip, const DevScene& S, const LdsStack& stk,
+                                                 int lane, uint32_t& tcnt) {
+  const uint32_t off = item_leaf & 0x7ffffff0u;
+  const float4* t0 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.tverts) + off);
+  const uint32_t leaf = item_leaf + 79u;  // next pair record (5 x 16 B), one pair fewer
+  bool in_a, in_b;
+  uint32_t idx_a;
+  pair_core(od, skip, t0, tcnt, in_a, in_b, idx_a);
+  const uint32_t owner = meta & 63u;
+  const uint32_t ocol = stk.col + (owner - (uint32_t)lane) * 4u;  // the owner's column
+  if (in_a || in_b) {  // rare.  A before B: within one leaf the order of the tests decides between equal distances
+    const uint32_t seq = meta >> 6;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (k == 0 ? in_a : in_b) {
+        float dist;
+        jvec3 P;
+        if (pair_hit(t0, k, od, &dist, &P)) {
+          // The lanes that hold a candidate for the same ray take turns: each writes its number into the owner's lock word,
+          // the one that reads its own number back goes first.  The loop runs until NO lane is left waiting (a ballot, the
+          // same for all of them): with a per-lane exit, the winner's stores become loop-exit code, which a wave runs once
+          // all its lanes have left the loop - the lanes of later turns would compare with a best hit not written yet.
+          bool waiting = true;
+          while (__ballot(waiting) != 0ull) {
+            if (waiting) {
+              const float bd = jade_u2f(lds_ld_v(ocol + TW_BEST_DIST * JADE_COL_STRIDE));
+              const uint32_t bs = lds_ld_v(ocol + TW_BEST_SEQ * JADE_COL_STRIDE);
+              if (!(dist < bd || (dist == bd && seq < bs))) {
+                waiting = false;
+              } else {
+                lds_st_v(ocol + TW_DUMMY * JADE_COL_STRIDE, (uint32_t)lane);
+                if (lds_ld_v(ocol + TW_DUMMY * JADE_COL_STRIDE) == (uint32_t)lane) {
+                  lds_st_v(ocol + TW_BEST_DIST * JADE_COL_STRIDE, jade_f2u(dist));
+                  lds_st_v(ocol + TW_BEST_SEQ * JADE_COL_STRIDE, seq);
+                  lds_st_v(ocol + TW_BEST_REF * JADE_COL_STRIDE, off | (uint32_t)k);
+                  waiting = false;
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  const bool fin = (leaf & 15u) == 0;
+  if (fin) __hip_atomic_fetch_add((jade_lds_u32*)(__SIZE_TYPE__)(ocol + TW_FINISHED * JADE_COL_STRIDE), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  item_leaf = fin ? 0u : leaf;
+}
+// The hit a finished ray reports: triangle index (-1 = miss), distance and hit point of the winning triangle.
+static __device__ __forceinline__ int32_t walk_result(const LdsStack& stk, const DevScene& S, const RayOD& od, float* dist, jvec3* P) {
+  const uint32_t ref = lds_get(stk, TW_BEST_REF);
+  *dist = lds_getf(stk, TW_BEST_DIST);
+  if (ref == 0xffffffffu) return -1;
+  const float4* t0 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.tverts) + (ref & 0x7ffffff0u));
+  const int k = (int)(ref & 1u);
+  float d2;
+  const jvec3 o = od_o(od), dn = od_dn(od);
+  const float* f = reinterpret_cast<const float*>(t0) + k;
+  const jvec3 p1 = jv(f[0], f[2], f[4]), p2 = jv(f[6], f[8], f[10]), p3 = jv(f[12], f[14], f[16]);
+  const jvec3 sa = jv_sub(p1, jv_scale(dn, jv_dot(dn, jv_sub(p1, o))));
+  const jvec3 sb = jv_sub(p2, jv_scale(dn, jv_dot(dn, jv_sub(p2, o))));
+  const jvec3 sc = jv_sub(p3, jv_scale(dn, jv_dot(dn, jv_sub(p3, o))));
+  tri_hit(p1, p2, p3, sa, sb, sc, o, dn, &d2, P);
+  return (int32_t)(jade_f2u(t0[4].z) + (uint32_t)k);
 }
