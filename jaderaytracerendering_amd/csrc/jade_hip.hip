@@ -398,11 +398,22 @@ static __device__ __forceinline__ void shade_tail(const PathState& P, int p, uin
       wd += sh_def[i];
     }
     if (LEAN && defer) heavy_out[wd] = (uint32_t)p;
-    if (live) {
-      if (active_out) active_out[wa] = (uint32_t)p;
-      const int used = (st == ST_DIFFUSE || st == ST_BSSRDF) ? P.nslots : 1;
-      for (int k = 0; k < used; ++k)
-        if (P.hit[(size_t)k * npix + p] == -1) queue[wq++] = (uint32_t)k * (uint32_t)npix + (uint32_t)p;
+    if (live && active_out) active_out[wa] = (uint32_t)p;
+    (void)wq;
+  }
+  {
+    // The wave's rays go into its stretch of the queue SLOT BY SLOT: all its records' slot-0 rays (shadow rays towards
+    // the first emitter), then the slot-1 rays, ...  The 64 entries a wave of k_trace takes are then one kind of ray from
+    // 64 neighbouring records - same target or same sky, origins side by side: they walk the same part of the tree
+    // (L1 hits) and end together - instead of the four rays of 16 records.
+    uint32_t wbase = sh_base[0];
+    for (int i = 0; i < w; ++i) wbase += sh_rays[i];
+    const int used = !live ? 0 : (st == ST_DIFFUSE || st == ST_BSSRDF) ? P.nslots : 1;
+    for (int k = 0; k < P.nslots; ++k) {
+      const bool q = k < used && P.hit[(size_t)k * npix + p] == -1;
+      const unsigned long long m = __ballot(q);
+      if (q) queue[wbase + (uint32_t)__popcll(m & below)] = (uint32_t)k * (uint32_t)npix + (uint32_t)p;
+      wbase += (uint32_t)__popcll(m);
     }
   }
   // work counters: per wave into LDS, then one set of atomics per block
@@ -495,7 +506,8 @@ __global__ __launch_bounds__(JADE_LEAN_BLOCK) void k_shade_lean(DevScene S, Path
 __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(DevScene S, PathState P, const uint32_t* queue, QueueCtl* qc,
                                                            uint32_t* spill, DevCounters* ctr, uint32_t chunk) {
   __shared__ uint32_t lds_cols[TW_END * JADE_TRACE_BLOCK];
-  __shared__ __attribute__((aligned(8))) uint32_t lds_wq[JADE_TRACE_BLOCK / 64][2 * JADE_WQ];  // a wave's queue of leaves to test (jade_trace.h)
+  __shared__ __attribute__((aligned(8))) uint32_t lds_wq[JADE_TRACE_BLOCK / 64][2 * JADE_WQ];  // a wave's ring of leaves to test (jade_trace.h)
+  __shared__ __attribute__((aligned(8))) uint32_t lds_hq[JADE_TRACE_BLOCK / 64][2 * JADE_HQ];  // and its ring of hit candidates  // a wave's queue of leaves to test (jade_trace.h)
   const int lane = threadIdx.x & 63;
   const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
   LdsStack stk;
@@ -505,16 +517,14 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
   stk.stride_spill = gridDim.x * blockDim.x;
   stk.top = nullptr;
   stk.top_k = 0;
-#if JADE_LDS_TOP_NODES > 0
-  __shared__ float4 lds_top[4 * JADE_LDS_TOP_NODES];
+  __shared__ float4 lds_top[4 * JADE_TRACE_TOP_NODES];
   {  // stage the top of the tree: record i's j-th 16 bytes -> plane j, entry i (coalesced reads of S.nodes)
-    const uint32_t k = S.top_k;  // <= JADE_LDS_TOP_NODES (jade_scene_create)
-    for (uint32_t i = threadIdx.x; i < 4u * k; i += JADE_TRACE_BLOCK) lds_top[(i & 3u) * JADE_LDS_TOP_NODES + (i >> 2)] = S.nodes[i];
+    const uint32_t k = S.top_k < JADE_TRACE_TOP_NODES ? S.top_k : JADE_TRACE_TOP_NODES;
+    for (uint32_t i = threadIdx.x; i < 4u * k; i += JADE_TRACE_BLOCK) lds_top[(i & 3u) * JADE_TRACE_TOP_NODES + (i >> 2)] = S.nodes[i];
     __syncthreads();
     stk.top = lds_top;
     stk.top_k = k;
   }
-#endif
   const uint32_t n = qc->count;
   if (chunk == 0) {  // batched passes: the host has not seen the queue length (trace_chunk's rule, on the device)
     const uint32_t waves = gridDim.x * (JADE_TRACE_BLOCK / 64);
@@ -543,11 +553,30 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
   r.pushed = 0;
   // the wave's ring of leaves to test: q_count items from q_head on (wave-uniform), and the item this lane is testing
   const uint32_t wq = lds_addr_of(&lds_wq[threadIdx.x >> 6][0]);
-  uint32_t q_head = 0, q_count = 0;
+  const uint32_t hq = lds_addr_of(&lds_hq[threadIdx.x >> 6][0]);
+  uint32_t q_head = 0, q_count = 0, h_head = 0, h_count = 0;
   uint32_t item_leaf = 0, item_meta = 0;
   const uint32_t lane_below_lo = lane < 32 ? (1u << lane) - 1u : 0xffffffffu, lane_below_hi = lane < 32 ? 0u : (1u << (lane - 32)) - 1u;
   auto rank_in = [&](unsigned long long m) -> uint32_t {  // lanes of m below this one
     return (uint32_t)__popc((uint32_t)m & lane_below_lo) + (uint32_t)__popc((uint32_t)(m >> 32) & lane_below_hi);
+  };
+  // resolve up to 64 of the waiting candidates, one per lane (jade_trace.h)
+  auto resolve_pass = [&]() {
+    const uint32_t nres = h_count < 64u ? h_count : 64u;
+    const bool mine = (uint32_t)lane < nres;
+    uint32_t ref = 0, meta = 0;
+    if (mine) lds_ld64(hq + ((h_head + (uint32_t)lane) & (JADE_HQ - 1u)) * 8u, ref, meta);
+    h_head = (h_head + nres) & (JADE_HQ - 1u);
+    h_count -= nres;
+    const int owner = (int)(meta & 63u);
+    RayOD od;
+    od.a.x = __shfl(r.od.a.x, owner, 64);
+    od.a.y = __shfl(r.od.a.y, owner, 64);
+    od.b.x = __shfl(r.od.b.x, owner, 64);
+    od.b.y = __shfl(r.od.b.y, owner, 64);
+    od.c.x = __shfl(r.od.c.x, owner, 64);
+    od.c.y = __shfl(r.od.c.y, owner, 64);
+    if (mine) resolve_hit(ref, meta, od, S, stk, lane);
   };
   for (;;) {
     // ---- a ray has ended when its walk has and all the leaves it pushed have been finished
@@ -615,6 +644,10 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
     const int nw = __popcll(__ballot(active && r.cur != JADE_REF_NONE));
     const uint32_t n_items = q_count + (uint32_t)__popcll(__ballot(item_leaf != 0));
     const uint32_t nt = n_items < 64u ? n_items : 64u;
+    if (nw == 0 && n_items == 0) {  // every ray in flight waits for candidates (fewer than a batch): resolve them now
+      if (h_count != 0) resolve_pass();
+      continue;
+    }
     if (q_count <= JADE_WQ - 64 && nw > 0 && JADE_COST_TRI * (uint32_t)nw >= JADE_COST_NODE * nt) {
       const bool general = S.general_walk || __ballot(active && (int32_t)r.skipx < 0) != 0ull;  // per WAVE (jade_trace.h)
 #pragma nounroll
@@ -624,6 +657,10 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
 #if JADE_TRACE_PROFILE == 1
         prof_units += 1;
         prof_lanes += (uint32_t)__popcll(__ballot(go));
+#endif
+#if JADE_TRACE_PROFILE == 4  /* node visits, and how many of them fall on the JADE_PROF_TOPK largest nodes */
+        prof_units += (uint32_t)__popcll(__ballot(go && (int32_t)r.cur >= 0));
+        prof_lanes += (uint32_t)__popcll(__ballot(go && r.cur < JADE_PROF_TOPK));
 #endif
         uint32_t leafv = 0;
         if (general) {
@@ -664,8 +701,11 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
         prof_units += 1;
         prof_lanes += (uint32_t)__popcll(__ballot(go));
 #endif
-        // the ray an item belongs to: seven registers of the lane that walks it (every lane executes the reads: ds_bpermute
-        // returns 0 for a source lane that is masked off)
+        // the record first (it depends on the item alone), then the ray the item belongs to: seven registers of the lane that
+        // walks it (every lane executes the reads: ds_bpermute returns 0 for a source lane that is masked off)
+        const uint32_t off = item_leaf & 0x7ffffff0u;
+        PairRec rec;
+        if (go) rec = pair_load(S, off);
         const int owner = (int)(item_meta & 63u);
         RayOD od;
         od.a.x = __shfl(r.od.a.x, owner, 64);
@@ -675,8 +715,22 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
         od.c.x = __shfl(r.od.c.x, owner, 64);
         od.c.y = __shfl(r.od.c.y, owner, 64);
         const uint32_t skip = (uint32_t)__shfl((int)r.skipx, owner, 64) & 0x7fffffffu;
-        if (go) test_step(item_leaf, item_meta, od, skip, S, stk, lane, tcnt);
+        bool in_a = false, in_b = false;
+        if (go) test_step(item_leaf, item_meta, od, skip, rec, stk, lane, tcnt, in_a, in_b);
+        // candidates (the origin projects into the triangle) are resolved later, many at a time
+        const unsigned long long ma = __ballot(in_a), mb = __ballot(in_b);
+        if (ma != 0ull) {
+          if (h_count > JADE_HQ - 64) resolve_pass();
+          if (in_a) lds_st64(hq + ((h_head + h_count + rank_in(ma)) & (JADE_HQ - 1u)) * 8u, off, item_meta);
+          h_count += (uint32_t)__popcll(ma);
+        }
+        if (mb != 0ull) {
+          if (h_count > JADE_HQ - 64) resolve_pass();
+          if (in_b) lds_st64(hq + ((h_head + h_count + rank_in(mb)) & (JADE_HQ - 1u)) * 8u, off | 1u, item_meta);
+          h_count += (uint32_t)__popcll(mb);
+        }
       }
+      if (h_count >= JADE_HQ_BATCH) resolve_pass();
     }
 #if JADE_TRACE_PROFILE == 3
     prof_units += 1;

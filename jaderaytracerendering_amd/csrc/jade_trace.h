@@ -77,7 +77,7 @@ struct LdsStack {
   uint32_t col;        // the same as an LDS byte address
   uint32_t* spill;     // global, spill[(level - JADE_LDS_STACK) * stride + gtid]
   uint32_t stride_spill;
-  const float4* top;   // LDS copy of node records [0, top_k): four planes of JADE_LDS_TOP_NODES float4 (plane j = the record's j-th 16 bytes)
+  const float4* top;   // LDS copy of node records [0, top_k): four planes of float4 (plane j = the record's j-th 16 bytes)
   uint32_t top_k;
 };
 enum {
@@ -244,7 +244,7 @@ static __device__ __forceinline__ jvec3 ray_hit_point(const LdsStack& stk) {
 // The core shared by the two forms of the walk (a FIFO of leaf cursors per lane: k_light; one queue of leaves per wave:
 // k_trace).  W_INV / W_DUMMY: where the column keeps 1/d and the dummy word.  room: a leaf met now can be taken.  Returns
 // the leaf met (0 = none); cur and sp advance.
-template <bool GENERAL, int W_INV, int W_DUMMY>
+template <bool GENERAL, int W_INV, int W_DUMMY, int TOPN>
 static __device__ __forceinline__ uint32_t node_core(uint32_t& cur_io, uint32_t& sp_io, const RayOD& od, const DevScene& S, const LdsStack& stk, bool room,
                                                      uint32_t& vcnt) {
   const uint32_t cur = cur_io;
@@ -261,7 +261,7 @@ static __device__ __forceinline__ uint32_t node_core(uint32_t& cur_io, uint32_t&
     // through a selected generic pointer (12 loads per visit instead of 4).
     const bool in_top = node < stk.top_k;
     const float4* t = stk.top + (in_top ? node : 0u);
-    const float4 la = t[0], lb = t[JADE_LDS_TOP_NODES], lc = t[2 * JADE_LDS_TOP_NODES], lr = t[3 * JADE_LDS_TOP_NODES];
+    const float4 la = t[0], lb = t[TOPN], lc = t[2 * TOPN], lr = t[3 * TOPN];
     a = la;
     b = lb;
     c = lc;
@@ -274,9 +274,14 @@ static __device__ __forceinline__ uint32_t node_core(uint32_t& cur_io, uint32_t&
       b = nd[1];
       c = nd[2];
       rf = *reinterpret_cast<const uint2*>(nd + 3);
-#if JADE_ABLATE_LOAD
+#if JADE_ABLATE_LOAD == 1
       {  // prices the vector-memory path: one more 16-B gather per lane from the line just fetched (+25 % look-ups, same bytes from L2)
         const float4 x = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(nd) + 40);
+        asm volatile("" ::"v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w));
+      }
+#elif JADE_ABLATE_LOAD == 2
+      {  // ... and from ANOTHER line (the neighbouring record): +25 % look-ups and +1 line from L2 per visit
+        const float4 x = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.nodes) + (node ^ 1u) * 64u);
         asm volatile("" ::"v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w));
       }
 #endif
@@ -346,7 +351,7 @@ static __device__ __forceinline__ uint32_t node_core(uint32_t& cur_io, uint32_t&
 // The walk with a FIFO of leaf cursors per lane (k_light): one unit for a lane with ray_can_walk.
 template <bool GENERAL>
 static __device__ __forceinline__ void ray_step_node_s(RayState& r, const DevScene& S, const LdsStack& stk, uint32_t& vcnt) {
-  const uint32_t leafv = node_core<GENERAL, LW_INVX, LW_DUMMY>(r.cur, r.sp, r.od, S, stk, leaf_room(r), vcnt);
+  const uint32_t leafv = node_core<GENERAL, LW_INVX, LW_DUMMY, JADE_LDS_TOP_NODES>(r.cur, r.sp, r.od, S, stk, leaf_room(r), vcnt);
   // the leaf met goes to the leaf cursor, or behind it into the FIFO
   const bool lq = (leafv & 15u) != 0;  // (an empty leaf cannot happen for a valid BVH)
   const bool to_fifo = lq && r.leaf != 0;
@@ -384,9 +389,22 @@ static __device__ __forceinline__ bool tri_hit(jvec3 p1, jvec3 p2, jvec3 p3, jve
 
 // The packed test of one pair record for one ray: is the projected origin inside the projected triangle A / B (:711-731)?
 // skip: the ray's source triangle.  tcnt: this lane's count of tests.
-static __device__ __forceinline__ void pair_core(const RayOD& od, uint32_t skip, const float4* t0, uint32_t& tcnt, bool& in_a_out, bool& in_b_out,
+struct PairRec {
+  float4 q0, q1, q2, q3, q4;
+};
+static __device__ __forceinline__ PairRec pair_load(const DevScene& S, uint32_t off) {
+  const float4* t0 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.tverts) + off);
+  PairRec p;
+  p.q0 = t0[0];
+  p.q1 = t0[1];
+  p.q2 = t0[2];
+  p.q3 = t0[3];
+  p.q4 = t0[4];
+  return p;
+}
+static __device__ __forceinline__ void pair_core(const RayOD& od, uint32_t skip, const PairRec& rec, uint32_t& tcnt, bool& in_a_out, bool& in_b_out,
                                                  uint32_t& idx_a_out) {
-  const float4 q0 = t0[0], q1 = t0[1], q2 = t0[2], q3 = t0[3], q4 = t0[4];
+  const float4 q0 = rec.q0, q1 = rec.q1, q2 = rec.q2, q3 = rec.q3, q4 = rec.q4;
   const uint32_t idx_a = jade_f2u(q4.z);
   const bool test_a = idx_a != skip, test_b = (jade_f2u(q4.w) & 1u) != 0 && idx_a + 1u != skip;
   tcnt += (test_a ? 1u : 0u) + (test_b ? 1u : 0u);
@@ -427,8 +445,12 @@ static __device__ __forceinline__ void pair_core(const RayOD& od, uint32_t skip,
 // held across the test for this block cost the kernel a wave per SIMD.
 static __device__ __forceinline__ bool pair_hit(const float4* t0, int k, const RayOD& od, float* dist, jvec3* P) {
   const jvec3 o = od_o(od), dn = od_dn(od);
-  const float* f = reinterpret_cast<const float*>(t0) + k;  // lane k of every pair
-  const jvec3 p1 = jv(f[0], f[2], f[4]), p2 = jv(f[6], f[8], f[10]), p3 = jv(f[12], f[14], f[16]);
+  // five 16-B loads and a select per component (nine 4-B loads would be nine trips through the L1's tag look-up)
+  const float4 q0 = t0[0], q1 = t0[1], q2 = t0[2], q3 = t0[3], q4 = t0[4];
+  const bool b = k != 0;
+  const jvec3 p1 = jv(b ? q0.y : q0.x, b ? q0.w : q0.z, b ? q1.y : q1.x);
+  const jvec3 p2 = jv(b ? q1.w : q1.z, b ? q2.y : q2.x, b ? q2.w : q2.z);
+  const jvec3 p3 = jv(b ? q3.y : q3.x, b ? q3.w : q3.z, b ? q4.y : q4.x);
   const jvec3 sa = jv_sub(p1, jv_scale(dn, jv_dot(dn, jv_sub(p1, o))));
   const jvec3 sb = jv_sub(p2, jv_scale(dn, jv_dot(dn, jv_sub(p2, o))));
   const jvec3 sc = jv_sub(p3, jv_scale(dn, jv_dot(dn, jv_sub(p3, o))));
@@ -442,7 +464,7 @@ static __device__ __forceinline__ void ray_step_tri_s(RayState& r, const DevScen
   const uint32_t leaf = r.leaf + 79u;  // next pair record (5 x 16 B), one pair fewer
   bool in_a, in_b;
   uint32_t idx_a;
-  pair_core(r.od, r.skipx & 0x7fffffffu, t0, tcnt, in_a, in_b, idx_a);
+  pair_core(r.od, r.skipx & 0x7fffffffu, pair_load(S, off), tcnt, in_a, in_b, idx_a);
   if (in_a || in_b) {  // A before B (index order, strict "<")
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -481,10 +503,13 @@ static __device__ __forceinline__ void ray_step_tri_s(RayState& r, const DevScen
 //   * a test iteration hands the queued items to the lanes in order - ALL lanes, also the ones that hold no ray or whose
 //     ray is through with its walk - one pair record per lane and unit, a leaf stays with its lane until it is finished;
 //   * hitArray's order (:776-792: leaves as the walk meets them, triangles by index, strict "<" so that the first of
-//     two equal distances wins) does not depend on WHEN a leaf is tested: a candidate replaces the owner's best hit if
-//     its distance is smaller, or equal with a smaller sequence number (within a leaf one lane tests in index order).
-//     Two lanes with candidates for the same ray in the same instruction take turns through a lock word in the owner's
-//     column;
+//     two equal distances wins) does not depend on WHEN a triangle is tested: a candidate replaces the owner's best hit
+//     if its distance is smaller, or equal with a smaller sequence number, or both equal and it comes earlier in the leaf;
+//   * the test itself only finds CANDIDATES (the origin projects into the triangle: one test in ten).  Solving for the
+//     hit point and the distance is 90 dependent instructions, and "one in ten" per lane is "nearly always" per wave: run
+//     inline, that block ran in every test unit for 3 lanes of 64 and was two thirds of the unit's instructions.  The
+//     candidates go into a second ring of the wave and are resolved 32-64 at a time (resolve_hit); two lanes with
+//     candidates for the same ray take turns through a lock word in the owner's column;
 //   * a ray has ended when its walk has and as many of its leaves have been finished (an LDS counter in its column,
 //     ds_add by whoever finishes one) as it pushed.  Its hit point is computed then, once, from the winning triangle
 //     (the same statements as in the test: same bits), instead of travelling with every candidate.
@@ -495,6 +520,13 @@ enum { TW_INVX = JADE_LDS_STACK, TW_INVY, TW_INVZ, TW_BEST_DIST, TW_BEST_SEQ, TW
 #define JADE_WQ 128 /* items a wave's ring holds (a power of two, >= 128: a walk unit may push 64) */
 #endif
 static_assert((JADE_WQ & (JADE_WQ - 1)) == 0 && JADE_WQ >= 128, "JADE_WQ");
+#ifndef JADE_HQ
+#define JADE_HQ 128 /* candidates a wave's second ring holds (a power of two, >= 128: a test unit may push 64 for A, then 64 for B) */
+#endif
+static_assert((JADE_HQ & (JADE_HQ - 1)) == 0 && JADE_HQ >= 128, "JADE_HQ");
+#ifndef JADE_HQ_BATCH
+#define JADE_HQ_BATCH 64 /* candidates waiting that trigger a resolve pass */
+#endif
 
 struct WalkState {
   RayOD od;         // origin and normalize(d)
@@ -528,59 +560,62 @@ static __device__ __forceinline__ void walk_begin(WalkState& r, const LdsStack& 
 // One unit of the walk for a lane whose walk has not ended.  Returns the leaf met (0 = none): the caller queues it.
 template <bool GENERAL>
 static __device__ __forceinline__ uint32_t walk_step(WalkState& r, const DevScene& S, const LdsStack& stk, uint32_t& vcnt) {
-  const uint32_t leafv = node_core<GENERAL, TW_INVX, TW_DUMMY>(r.cur, r.sp, r.od, S, stk, true, vcnt);
+  const uint32_t leafv = node_core<GENERAL, TW_INVX, TW_DUMMY, JADE_TRACE_TOP_NODES>(r.cur, r.sp, r.od, S, stk, true, vcnt);
   return (leafv & 15u) != 0 ? leafv : 0u;  // (an empty leaf cannot happen for a valid BVH)
 }
 
 // One pair record of the item a lane holds: item_leaf = the leaf cursor (0 afterwards if the leaf is finished), meta =
-// owner lane | sequence << 6, od / skip = the owner's ray (the caller's ds_bpermute), lane = this lane.
-static __device__ __forceinline__ void test_step(uint32_t& item_leaf, uint32_t meta, const RayOD& od, uint32_t skip, const DevScene& S, const LdsStack& stk,
-                                                 int lane, uint32_t& tcnt) {
-  const uint32_t off = item_leaf & 0x7ffffff0u;
-  const float4* t0 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.tverts) + off);
+// owner lane | sequence << 6, od / skip = the owner's ray (the caller's ds_bpermute), rec = the record (the caller's
+// pair_load, issued before the ds_bpermutes so that the two latencies overlap), lane = this lane.  in_a / in_b: the origin
+// projects into triangle A / B of the record - a candidate the caller queues (resolve_hit).
+static __device__ __forceinline__ void test_step(uint32_t& item_leaf, uint32_t meta, const RayOD& od, uint32_t skip, const PairRec& rec, const LdsStack& stk,
+                                                 int lane, uint32_t& tcnt, bool& in_a, bool& in_b) {
   const uint32_t leaf = item_leaf + 79u;  // next pair record (5 x 16 B), one pair fewer
-  bool in_a, in_b;
   uint32_t idx_a;
-  pair_core(od, skip, t0, tcnt, in_a, in_b, idx_a);
-  const uint32_t owner = meta & 63u;
-  const uint32_t ocol = stk.col + (owner - (uint32_t)lane) * 4u;  // the owner's column
-  if (in_a || in_b) {  // rare.  A before B: within one leaf the order of the tests decides between equal distances
-    const uint32_t seq = meta >> 6;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      if (k == 0 ? in_a : in_b) {
-        float dist;
-        jvec3 P;
-        if (pair_hit(t0, k, od, &dist, &P)) {
-          // The lanes that hold a candidate for the same ray take turns: each writes its number into the owner's lock word,
-          // the one that reads its own number back goes first.  The loop runs until NO lane is left waiting (a ballot, the
-          // same for all of them): with a per-lane exit, the winner's stores become loop-exit code, which a wave runs once
-          // all its lanes have left the loop - the lanes of later turns would compare with a best hit not written yet.
-          bool waiting = true;
-          while (__ballot(waiting) != 0ull) {
-            if (waiting) {
-              const float bd = jade_u2f(lds_ld_v(ocol + TW_BEST_DIST * JADE_COL_STRIDE));
-              const uint32_t bs = lds_ld_v(ocol + TW_BEST_SEQ * JADE_COL_STRIDE);
-              if (!(dist < bd || (dist == bd && seq < bs))) {
-                waiting = false;
-              } else {
-                lds_st_v(ocol + TW_DUMMY * JADE_COL_STRIDE, (uint32_t)lane);
-                if (lds_ld_v(ocol + TW_DUMMY * JADE_COL_STRIDE) == (uint32_t)lane) {
-                  lds_st_v(ocol + TW_BEST_DIST * JADE_COL_STRIDE, jade_f2u(dist));
-                  lds_st_v(ocol + TW_BEST_SEQ * JADE_COL_STRIDE, seq);
-                  lds_st_v(ocol + TW_BEST_REF * JADE_COL_STRIDE, off | (uint32_t)k);
-                  waiting = false;
-                }
-              }
-            }
-          }
+  pair_core(od, skip, rec, tcnt, in_a, in_b, idx_a);
+  const uint32_t ocol = stk.col + ((meta & 63u) - (uint32_t)lane) * 4u;  // the owner's column
+  // the ray must not end before its candidates are resolved: each takes one off the finished-leaf count until then
+  const uint32_t n_cand = (in_a ? 1u : 0u) + (in_b ? 1u : 0u);
+  const bool fin = (leaf & 15u) == 0;
+  const uint32_t delta = (fin ? 1u : 0u) - n_cand;
+  if (delta != 0u)
+    __hip_atomic_fetch_add((jade_lds_u32*)(__SIZE_TYPE__)(ocol + TW_FINISHED * JADE_COL_STRIDE), delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  item_leaf = fin ? 0u : leaf;
+}
+// A candidate: triangle (ref & 1) of the pair record at ref & ~15 against the ray of lane meta & 63 (od), a leaf the ray
+// met as its (meta >> 6)-th.  The barycentric solve and the distance (:732-747), then hitArray's rule for the best hit
+// (:787, strict "<" in the order leaves are met and triangles are indexed), which in terms of the candidates is: smaller
+// distance, then earlier leaf, then earlier triangle of the leaf (ref grows with the index inside a leaf).
+static __device__ __forceinline__ void resolve_hit(uint32_t ref, uint32_t meta, const RayOD& od, const DevScene& S, const LdsStack& stk, int lane) {
+  const float4* t0 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.tverts) + (ref & 0x7ffffff0u));
+  const uint32_t ocol = stk.col + ((meta & 63u) - (uint32_t)lane) * 4u;  // the owner's column
+  const uint32_t seq = meta >> 6;
+  float dist;
+  jvec3 P;
+  // The lanes that hold a candidate for the same ray take turns: each writes its number into the owner's lock word, the
+  // one that reads its own number back goes first.  The loop runs until NO lane is left waiting (a ballot, the same for all
+  // of them): with a per-lane exit, the winner's stores become loop-exit code, which a wave runs once all its lanes have
+  // left the loop - the lanes of later turns would compare with a best hit not written yet.
+  bool waiting = pair_hit(t0, (int)(ref & 1u), od, &dist, &P);
+  while (__ballot(waiting) != 0ull) {
+    if (waiting) {
+      const float bd = jade_u2f(lds_ld_v(ocol + TW_BEST_DIST * JADE_COL_STRIDE));
+      const uint32_t bs = lds_ld_v(ocol + TW_BEST_SEQ * JADE_COL_STRIDE);
+      const uint32_t br = lds_ld_v(ocol + TW_BEST_REF * JADE_COL_STRIDE);
+      if (!(dist < bd || (dist == bd && (seq < bs || (seq == bs && ref < br))))) {
+        waiting = false;
+      } else {
+        lds_st_v(ocol + TW_DUMMY * JADE_COL_STRIDE, (uint32_t)lane);
+        if (lds_ld_v(ocol + TW_DUMMY * JADE_COL_STRIDE) == (uint32_t)lane) {
+          lds_st_v(ocol + TW_BEST_DIST * JADE_COL_STRIDE, jade_f2u(dist));
+          lds_st_v(ocol + TW_BEST_SEQ * JADE_COL_STRIDE, seq);
+          lds_st_v(ocol + TW_BEST_REF * JADE_COL_STRIDE, ref);
+          waiting = false;
         }
       }
     }
   }
-  const bool fin = (leaf & 15u) == 0;
-  if (fin) __hip_atomic_fetch_add((jade_lds_u32*)(__SIZE_TYPE__)(ocol + TW_FINISHED * JADE_COL_STRIDE), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-  item_leaf = fin ? 0u : leaf;
+  __hip_atomic_fetch_add((jade_lds_u32*)(__SIZE_TYPE__)(ocol + TW_FINISHED * JADE_COL_STRIDE), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 // The hit a finished ray reports: triangle index (-1 = miss), distance and hit point of the winning triangle.
 static __device__ __forceinline__ int32_t walk_result(const LdsStack& stk, const DevScene& S, const RayOD& od, float* dist, jvec3* P) {
@@ -590,12 +625,6 @@ static __device__ __forceinline__ int32_t walk_result(const LdsStack& stk, const
   const float4* t0 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.tverts) + (ref & 0x7ffffff0u));
   const int k = (int)(ref & 1u);
   float d2;
-  const jvec3 o = od_o(od), dn = od_dn(od);
-  const float* f = reinterpret_cast<const float*>(t0) + k;
-  const jvec3 p1 = jv(f[0], f[2], f[4]), p2 = jv(f[6], f[8], f[10]), p3 = jv(f[12], f[14], f[16]);
-  const jvec3 sa = jv_sub(p1, jv_scale(dn, jv_dot(dn, jv_sub(p1, o))));
-  const jvec3 sb = jv_sub(p2, jv_scale(dn, jv_dot(dn, jv_sub(p2, o))));
-  const jvec3 sc = jv_sub(p3, jv_scale(dn, jv_dot(dn, jv_sub(p3, o))));
-  tri_hit(p1, p2, p3, sa, sb, sc, o, dn, &d2, P);
+  pair_hit(t0, k, od, &d2, P);
   return (int32_t)(jade_f2u(t0[4].z) + (uint32_t)k);
 }
