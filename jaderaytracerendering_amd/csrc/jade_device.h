@@ -55,7 +55,7 @@
 #define JADE_TRACE_BLOCK 256
 #endif
 #ifndef JADE_TRACE_TOP_NODES
-#define JADE_TRACE_TOP_NODES 96 /* k_trace's share of the top (<= JADE_LDS_TOP_NODES): 16 KB of columns + 8 KB of rings + 6 KB of nodes = 30 KB, 5 blocks per CU */
+#define JADE_TRACE_TOP_NODES 160 /* k_trace's share of the top (<= JADE_LDS_TOP_NODES): 16 KB of columns + 8 KB of rings + 10 KB of nodes = 34 KB, 4 blocks per CU.  96 nodes (30 KB, 5 blocks): the same speed on C3, 5 % slower on C5; 224: no better */
 #endif
 #ifndef JADE_LDS_TOP_NODES  /* 0 = no staging (A/B builds); 5 blocks x (21 KB of columns + 10 KB of nodes) = 155 of the CU's 160 KB */
 #define JADE_LDS_TOP_NODES 160 /* k_light's; k_trace per 1024-spp step of C3 (round 2, FIFO form): 570 ms without, 552 with 80, 545 with 160 */

@@ -501,7 +501,7 @@ __global__ __launch_bounds__(JADE_LEAN_BLOCK) void k_shade_lean(DevScene S, Path
 #define JADE_COST_TRI 120  /* ... and by a triangle-test iteration (k_trace picks the kind per wave iteration) */
 #endif
 #ifndef JADE_TRACE_WAVES
-#define JADE_TRACE_WAVES 5 /* waves per SIMD the register allocation must leave room for: the pair-packed triangle test wants 104 VGPRs, at 92 (no scratch) a fifth wave fits and k_trace is 8 % faster */
+#define JADE_TRACE_WAVES 4 /* waves per SIMD the register allocation leaves room for: k_trace's LDS (34 KB per block) admits 4 blocks per CU; 4 and 5 blocks run at the same speed (the kernel is bound by latency and by L2 line fetches, not by issue: DESIGN.md 3.4) */
 #endif
 __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(DevScene S, PathState P, const uint32_t* queue, QueueCtl* qc,
                                                            uint32_t* spill, DevCounters* ctr, uint32_t chunk) {

@@ -306,6 +306,35 @@ def test_trace_rays_bit_exact(oracle, hip, name):
     assert (st_o.nodes_visited, st_o.tris_tested) == (st_h.nodes_visited, st_h.tris_tested)
 
 
+def test_trace_rays_equal_distances_keep_the_first_in_walk_order(oracle, hip):
+    """Every triangle of this scene exists twice at the same place (two copies of one object), so nearly every hit has a
+    twin at exactly the same distance, most of them in another leaf.  hitArray keeps the first one it meets (strict "<",
+    PathTrace.cu:787; leaves in walk order, :806-856): k_trace tests the leaves of a ray on whatever lanes are free and in
+    any order, and has to end up with the same triangle - the (distance, leaf sequence, place in the leaf) rule of
+    resolve_hit."""
+    from jaderaytracerendering_amd import host as H
+    b = J.SceneBuilder()
+    b.config("tiny")
+    mat = H.material(brdf=(0.5,) * 3)
+    for _ in range(2):
+        b.add_proc("geodesic", 3, mat, H.transform_matrix(trans=(0.1, -1.2, 1.0), scale=(1.1, 1.1, 1.1)))
+    b.set_env_sky(16, 8)
+    hs = b.build()
+    o, d, skip = _random_rays(hs, 60000, 77)
+    skip[:] = -1
+    with oracle.scene(hs) as so, hip.scene(hs) as sh:
+        i_o, t_o, p_o, st_o = so.trace_rays(o, d, skip)
+        i_h, t_h, p_h, st_h = sh.trace_rays(o, d, skip)
+    hitm = i_o >= 0
+    # the twins make ties common: count the hits whose distance some OTHER triangle reaches too is not possible from here,
+    # but an index mismatch with equal distances is exactly what a wrong tie rule would produce
+    assert hitm.sum() > 1000
+    assert np.array_equal(t_o.view(np.uint32), t_h.view(np.uint32))
+    assert np.array_equal(i_o, i_h)
+    assert np.array_equal(p_o[hitm].view(np.uint32), p_h[hitm].view(np.uint32))
+    assert (st_o.nodes_visited, st_o.tris_tested) == (st_h.nodes_visited, st_h.tris_tested)
+
+
 def test_refraction_material(oracle, hip):
     """DIR_REFRACT (refract_mode 2, PathTrace.cu:1180-1262): a glass ball in the Cornell box."""
     from jaderaytracerendering_amd import host as H
