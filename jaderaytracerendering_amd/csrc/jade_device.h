@@ -118,14 +118,15 @@ struct PathState {
   float* src;           // [3][npix] current vertex position
   float* out;           // [3][npix] direction back toward the previous vertex
   float eye[3];         // origin of every camera ray (skip == JADE_SKIP_CAMERA): not stored per record
-  float* org;           // [3][npix] origin shared by this pixel's pending rays
-  int32_t* skip;        // source triangle of the pending rays
+  float4* orgs;         // [npix] {origin shared by this record's pending rays, source triangle of those rays (int bits)}
   float* aux;           // [3][npix] BSSRDF profile / refraction attenuation
   int32_t* auxi;        // refraction: iteration counter
-  float* dir;           // [3][nslots][npix] pending ray directions
-  int32_t* hit;         // [nslots][npix] -2 inactive, -1 miss, >= 0 triangle
-  float* hpt;           // [3][nslots][npix] hit points
-  float* hdist;         // [nslots][npix] HitResult.distance of the best hit as k_trace compared it; null in renders (nothing reads it), set by jade_trace_rays
+  // Ray slots, two float4 per slot and a record's slots side by side: slot[(p * nslots + k) * 2] = {direction, hit (int bits:
+  // -2 inactive, -1 queued / miss, >= 0 triangle)}, [.. + 1] = {hit point, HitResult.distance of the best hit as k_trace
+  // compared it}.  A ray is one 16-B read and one 32-B sector written for k_trace, and a record's whole bounce (nslots rays
+  // out, nslots results back) is one or two cache lines for k_shade - as planes (round 1) it was a line per component:
+  // 28 lines per record and pass once the active list had thinned out.  A queue entry is the slot number p * nslots + k.
+  float4* slot;
 };
 
 enum : uint32_t {

@@ -188,9 +188,9 @@ static __device__ __forceinline__ void shade_record(const DevScene& S, const Pat
   const uint32_t word = P.stage[pp];
   const uint32_t rng0 = P.rng[pp];
   const uint32_t done0 = P.done[pp];
-  const int hit0 = P.hit[pp];
-  const size_t pl0 = (size_t)P.nslots * npix;
-  const jvec3 dir0 = jv(P.dir[pp], P.dir[pl0 + pp], P.dir[2 * pl0 + pp]);
+  const float4 slot0 = P.slot[(size_t)pp * P.nslots * 2];  // slot 0: {direction, hit}
+  const int hit0 = __float_as_int(slot0.w);
+  const jvec3 dir0 = jv(slot0.x, slot0.y, slot0.z);
   const uint32_t rec_m = (uint32_t)pp / (uint32_t)P.npx;
   const int home_pix = (int)((uint32_t)pp - rec_m * (uint32_t)P.npx);
   const int tid0 = tile_ids[home_pix >> 8];
@@ -315,7 +315,7 @@ static __device__ __forceinline__ void shade_record(const DevScene& S, const Pat
         float up_offset = (float)(-1.0 + R.two_over_h * ((double)fy - 0.5));
         jvec3 dir = jade_transform(jv(left_offset, up_offset, -1.5f), 0.0f, R.cam);
         dir = jv_normalize(dir);
-        P.skip[p] = JADE_SKIP_CAMERA;  // no source triangle, and the origin is the eye: k_trace takes it from P.eye
+        reinterpret_cast<int*>(P.orgs + p)[3] = JADE_SKIP_CAMERA;  // no source triangle, and the origin is the eye: k_trace takes it from P.eye
         px.set_dir(0, dir);
         px.set_hit(0, -1);
         c.n_emit_rays = 1;
@@ -361,7 +361,6 @@ static __device__ __forceinline__ void shade_tail(const PathState& P, int p, uin
                                                   DevCounters* ctr) {
   __shared__ uint32_t sh_rays[NW], sh_act[NW], sh_def[NW], sh_base[3];
   __shared__ uint32_t sh_ctr[NW][8];
-  const int npix = P.npix;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   uint32_t total;
   const uint32_t off = wave_excl_scan((uint32_t)c.n_emit_rays, &total);
@@ -410,9 +409,9 @@ static __device__ __forceinline__ void shade_tail(const PathState& P, int p, uin
     for (int i = 0; i < w; ++i) wbase += sh_rays[i];
     const int used = !live ? 0 : (st == ST_DIFFUSE || st == ST_BSSRDF) ? P.nslots : 1;
     for (int k = 0; k < P.nslots; ++k) {
-      const bool q = k < used && P.hit[(size_t)k * npix + p] == -1;
+      const bool q = k < used && reinterpret_cast<const int*>(P.slot + ((size_t)p * P.nslots + k) * 2)[3] == -1;
       const unsigned long long m = __ballot(q);
-      if (q) queue[wbase + (uint32_t)__popcll(m & below)] = (uint32_t)k * (uint32_t)npix + (uint32_t)p;
+      if (q) queue[wbase + (uint32_t)__popcll(m & below)] = (uint32_t)p * (uint32_t)P.nslots + (uint32_t)k;
       wbase += (uint32_t)__popcll(m);
     }
   }
@@ -488,6 +487,15 @@ __global__ __launch_bounds__(JADE_LEAN_BLOCK) void k_shade_lean(DevScene S, Path
 #define NT_LD(p) (*(p))
 #define NT_ST(p, v) (*(p) = (v))
 #endif
+typedef float jade_v4f __attribute__((ext_vector_type(4)));
+static __device__ __forceinline__ float4 nt_ld4(const float4* p) {
+  const jade_v4f v = NT_LD(reinterpret_cast<const jade_v4f*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+static __device__ __forceinline__ void nt_st4(float4* p, float x, float y, float z, float w) {
+  const jade_v4f v = {x, y, z, w};
+  NT_ST(reinterpret_cast<jade_v4f*>(p), v);
+}
 #ifndef JADE_TRACE_PROFILE
 #define JADE_TRACE_PROFILE 0
 #endif
@@ -532,8 +540,6 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
     per = per < 1u ? 1u : (per > JADE_TRACE_CHUNK / 64 ? JADE_TRACE_CHUNK / 64 : per);
     chunk = per * 64u;
   }
-  const int npix = P.npix;
-  const size_t plane = (size_t)P.nslots * npix;
   uint32_t V = 0, T = 0;  // wave totals (uniform: they live in SGPRs)
   uint32_t vcnt = 0, tcnt = 0;  // per lane, summed over the wave once at the end (a ballot + popcount per unit was 8 instructions)
 #if JADE_TRACE_PROFILE
@@ -544,7 +550,7 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
   bool queue_empty = false;
   bool active = false;  // this lane walks a ray, or waits for the last of its leaves to be tested
   bool wb = false;      // this lane's ray has ended and its result is still in the LDS column
-  uint32_t my_e = 0;    // this lane's queue entry: slot * npix + record
+  uint32_t my_e = 0;    // this lane's queue entry: the slot number, record * nslots + slot
   WalkState r;
   r.od.a = r.od.b = r.od.c = f2{0.0f, 0.0f};
   r.skipx = 0;
@@ -594,16 +600,11 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
         // ray records stream through once per pass: non-temporal, so that they do not push the BVH out of the XCD's
         // 4 MB L2 (C3's node + vertex records are 4.1 MB; PMC: 124 of the 172 HBM bytes per ray were BVH lines re-fetched)
         float dist;
-        jvec3 hp;
+        jvec3 hp = jv(0, 0, 0);
         const int32_t best = walk_result(stk, S, r.od, &dist, &hp);
-        NT_ST(&P.hit[my_e], best);
-        if (P.hdist) P.hdist[my_e] = dist;  // wave-uniform: only jade_trace_rays asks for it
-        if (best >= 0) {  // the hit point of a miss is never read
-          float* hb = P.hpt + my_e;
-          NT_ST(&hb[0], hp.x);
-          NT_ST(&hb[plane], hp.y);
-          NT_ST(&hb[2 * plane], hp.z);
-        }
+        float4* sl = P.slot + (size_t)my_e * 2;
+        NT_ST(reinterpret_cast<int32_t*>(sl) + 3, best);
+        nt_st4(sl + 1, hp.x, hp.y, hp.z, dist);  // (the hit point of a miss is never read; its distance stays INF, PathTrace.cu:799)
         wb = false;
       }
       if (!queue_empty) {
@@ -624,12 +625,12 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
         const uint32_t rank = rank_in(idle);
         if (!active && rank < take) {
           my_e = NT_LD(&queue[lbase + rank]);
-          const uint32_t k = my_e / (uint32_t)npix, p = my_e - k * (uint32_t)npix;
-          const int32_t skip = NT_LD(&P.skip[p]);
-          const jvec3 o = skip == JADE_SKIP_CAMERA ? jv(P.eye[0], P.eye[1], P.eye[2])
-                                                   : jv(NT_LD(&P.org[p]), NT_LD(&P.org[npix + p]), NT_LD(&P.org[2 * npix + p]));
-          const float* db = P.dir + my_e;
-          const jvec3 d = jv(NT_LD(&db[0]), NT_LD(&db[plane]), NT_LD(&db[2 * plane]));
+          const uint32_t p = my_e / (uint32_t)P.nslots;  // the entry is the slot number p * nslots + k
+          const float4 og = nt_ld4(&P.orgs[p]);
+          const int32_t skip = __float_as_int(og.w);
+          const jvec3 o = skip == JADE_SKIP_CAMERA ? jv(P.eye[0], P.eye[1], P.eye[2]) : jv(og.x, og.y, og.z);
+          const float4 dv = nt_ld4(&P.slot[(size_t)my_e * 2]);
+          const jvec3 d = jv(dv.x, dv.y, dv.z);
           walk_begin(r, stk, S, o, d, skip);
           active = true;
         }
@@ -1522,8 +1523,8 @@ static int setup_state(jade_scene* s, int npx, int rpp, int nslots) {
   auto take = [&](size_t n) { size_t o = words; words += (n + 63) & ~(size_t)63; return o; };
   const size_t N = (size_t)npix, K = (size_t)nslots;
   size_t o_rng = take(N), o_done = take(N), o_stage = take(N), o_sum = take(3 * (size_t)JADE_SAMPLE_LANES * npx), o_thr = take(3 * N), o_acc = take(3 * N),
-         o_le = take(3 * N), o_obj = take(N), o_src = take(3 * N), o_out = take(3 * N), o_org = take(3 * N), o_skip = take(N),
-         o_aux = take(3 * N), o_auxi = take(N), o_dir = take(3 * K * N), o_hit = take(K * N), o_hpt = take(3 * K * N);
+         o_le = take(3 * N), o_obj = take(N), o_src = take(3 * N), o_out = take(3 * N), o_orgs = take(4 * N),
+         o_aux = take(3 * N), o_auxi = take(N), o_slot = take(8 * K * N);
   HIP_TRY(s->b_state.alloc(words * 4));
   HIP_TRY(hipMemsetAsync(s->b_state.p, 0, words * 4, s->stream));
   uint32_t* b = s->b_state.as<uint32_t>();
@@ -1542,9 +1543,9 @@ static int setup_state(jade_scene* s, int npx, int rpp, int nslots) {
   P.nslots = nslots;
   P.rng = b + o_rng; P.done = b + o_done; P.stage = b + o_stage;
   P.sum = (float*)(b + o_sum); P.thr = (float*)(b + o_thr); P.acc = (float*)(b + o_acc); P.le = (float*)(b + o_le);
-  P.obj = (int32_t*)(b + o_obj); P.src = (float*)(b + o_src); P.out = (float*)(b + o_out); P.org = (float*)(b + o_org);
-  P.skip = (int32_t*)(b + o_skip); P.aux = (float*)(b + o_aux); P.auxi = (int32_t*)(b + o_auxi);
-  P.dir = (float*)(b + o_dir); P.hit = (int32_t*)(b + o_hit); P.hpt = (float*)(b + o_hpt);
+  P.obj = (int32_t*)(b + o_obj); P.src = (float*)(b + o_src); P.out = (float*)(b + o_out); P.orgs = (float4*)(b + o_orgs);
+  P.aux = (float*)(b + o_aux); P.auxi = (int32_t*)(b + o_auxi);
+  P.slot = (float4*)(b + o_slot);
   HIP_TRY(s->b_queue.alloc(K * N * 4));
   // b_active[0] doubles as k_light's per-wave hand-over regions: up to 64 records of slack per wave of its grid
   HIP_TRY(s->b_active[0].alloc((N + (size_t)s->light_blocks * JADE_TRACE_BLOCK + 64) * 4));
@@ -1570,7 +1571,7 @@ int jade_render_begin(jade_scene* s, const jade_render_params* rp) {
   // Records per pixel: as many paths in flight as JADE_RECORD_MEMORY of the free device memory holds (the
   // partial sums come out of the same share), whatever the image share of this GPU: more records = fewer,
   // wider passes.  288 GB is what makes 530 M paths (112 GB) for a full 1080p frame affordable.
-  const double bytes_per_record = 4.0 * (29 + 8 * nslots);  // PathState + queue entry + two list entries
+  const double bytes_per_record = 4.0 * (29 + 9 * nslots);  // PathState (a slot is two float4) + queue entry + two list entries
   const double sums_bytes = 12.0 * JADE_SAMPLE_LANES * (double)npx64;
   size_t mem_free = 0, mem_total = 0;
   HIP_TRY(hipMemGetInfo(&mem_free, &mem_total));
@@ -2150,30 +2151,29 @@ int jade_trace_rays(jade_scene* s, int32_t n, const float* origins, const float*
   HIP_TRY(hipSetDevice(s->device));
   // a throw-away PathState with one slot per "pixel"
   const size_t N = (size_t)n;
-  std::vector<float> so(3 * N), sd(3 * N);
-  for (size_t i = 0; i < N; ++i)
-    for (int c = 0; c < 3; ++c) { so[c * N + i] = origins[3 * i + c]; sd[c * N + i] = dirs[3 * i + c]; }
+  std::vector<float4> so(N), sl(2 * N);
+  for (size_t i = 0; i < N; ++i) {
+    const int32_t sk = skip[i] < 0 ? -1 : skip[i];  // any negative value means "no source triangle" (the device keeps -2 for camera rays)
+    float skf, qf;
+    const int32_t queued = -1;
+    memcpy(&skf, &sk, 4);
+    memcpy(&qf, &queued, 4);
+    so[i] = make_float4(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2], skf);
+    sl[2 * i] = make_float4(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], qf);
+    sl[2 * i + 1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // the hit point of a miss is reported as zeros
+  }
   std::vector<uint32_t> q(N);
   for (size_t i = 0; i < N; ++i) q[i] = (uint32_t)i;
-  DevBuf b_org, b_dir, b_skip, b_hit, b_hpt, b_q, b_spill;
-  HIP_TRY(upload(b_org, so.data(), so.size(), s->stream));
-  HIP_TRY(upload(b_dir, sd.data(), sd.size(), s->stream));
-  std::vector<int32_t> sk(skip, skip + N);
-  for (int32_t& v : sk)
-    if (v < 0) v = -1;  // any negative value means "no source triangle" (the device keeps -2 for camera rays)
-  HIP_TRY(upload(b_skip, sk.data(), N, s->stream));
-  DevBuf b_hdist;
-  HIP_TRY(b_hit.alloc(N * 4));
-  HIP_TRY(b_hpt.alloc(3 * N * 4));
-  HIP_TRY(b_hdist.alloc(N * 4));
-  HIP_TRY(hipMemsetAsync(b_hpt.p, 0, 3 * N * 4, s->stream));  // the hit point of a miss is never written: report zeros
+  DevBuf b_orgs, b_slot, b_q, b_spill;
+  HIP_TRY(upload(b_orgs, so.data(), so.size(), s->stream));
+  HIP_TRY(upload(b_slot, sl.data(), sl.size(), s->stream));
   HIP_TRY(upload(b_q, q.data(), N, s->stream));
   HIP_TRY(b_spill.alloc((size_t)(JADE_BVH_STACK_CAPACITY - JADE_LDS_STACK) * s->trace_blocks * JADE_TRACE_BLOCK * 4));
   PathState P{};
   P.npix = n;
   P.nslots = 1;
-  P.org = b_org.as<float>(); P.dir = b_dir.as<float>(); P.skip = b_skip.as<int32_t>();
-  P.hit = b_hit.as<int32_t>(); P.hpt = b_hpt.as<float>(); P.hdist = b_hdist.as<float>();
+  P.orgs = b_orgs.as<float4>();
+  P.slot = b_slot.as<float4>();
   // everything on the scene's own (non-blocking) stream: the null stream does not order against it
   QueueCtl qc{};
   qc.count = (uint32_t)n;
@@ -2190,18 +2190,19 @@ int jade_trace_rays(jade_scene* s, int32_t n, const float* origins, const float*
   HIP_TRY(hipEventSynchronize(ev1.e));
   float ms = 0;
   HIP_TRY(hipEventElapsedTime(&ms, ev0.e, ev1.e));
-  std::vector<float> hp(3 * N);
-  HIP_TRY(hipMemcpyAsync(hit_index, b_hit.p, N * 4, hipMemcpyDeviceToHost, s->stream));
-  HIP_TRY(hipMemcpyAsync(hp.data(), b_hpt.p, 3 * N * 4, hipMemcpyDeviceToHost, s->stream));
   // HitResult.distance (PathTrace.cu:740) exactly as the kernel compared it (hitArray's `<`, :787); a miss keeps INF (:799)
-  if (hit_dist) HIP_TRY(hipMemcpyAsync(hit_dist, b_hdist.p, N * 4, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipMemcpyAsync(sl.data(), b_slot.p, 2 * N * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
-  if (hit_point)
-    for (size_t i = 0; i < N; ++i) {
-      hit_point[3 * i] = hp[i];
-      hit_point[3 * i + 1] = hp[N + i];
-      hit_point[3 * i + 2] = hp[2 * N + i];
+  for (size_t i = 0; i < N; ++i) {
+    memcpy(&hit_index[i], &sl[2 * i].w, 4);
+    if (hit_dist) hit_dist[i] = sl[2 * i + 1].w;
+    if (hit_point) {
+      const bool hit = hit_index[i] >= 0;
+      hit_point[3 * i] = hit ? sl[2 * i + 1].x : 0.0f;
+      hit_point[3 * i + 1] = hit ? sl[2 * i + 1].y : 0.0f;
+      hit_point[3 * i + 2] = hit ? sl[2 * i + 1].z : 0.0f;
     }
+  }
   if (st) {
     DevCounters c{};
     HIP_TRY(sum_counters(s, &c));

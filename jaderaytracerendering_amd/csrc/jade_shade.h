@@ -108,28 +108,29 @@ struct Px {
   const PathState& P;
   int p;
   __device__ Px(const PathState& ps, int pix) : P(ps), p(pix) {}
+  // the record's ray slots: two float4 per slot, side by side per record (jade_device.h)
+  __device__ float4* slot(int k) const { return P.slot + ((size_t)p * P.nslots + k) * 2; }
   __device__ jvec3 dir(int k) const {
-    const float* b = P.dir + (size_t)k * P.npix;
-    const size_t pl = (size_t)P.nslots * P.npix;
-    return jv(b[p], b[pl + p], b[2 * pl + p]);
+    const float4 v = slot(k)[0];
+    return jv(v.x, v.y, v.z);
   }
   __device__ void set_dir(int k, jvec3 v) const {
-    float* b = P.dir + (size_t)k * P.npix;
-    const size_t pl = (size_t)P.nslots * P.npix;
-    b[p] = v.x; b[pl + p] = v.y; b[2 * pl + p] = v.z;
+    float* f = reinterpret_cast<float*>(slot(k));
+    f[0] = v.x; f[1] = v.y; f[2] = v.z;
   }
   __device__ jvec3 hpt(int k) const {
-    const float* b = P.hpt + (size_t)k * P.npix;
-    const size_t pl = (size_t)P.nslots * P.npix;
-    return jv(b[p], b[pl + p], b[2 * pl + p]);
+    const float4 v = slot(k)[1];
+    return jv(v.x, v.y, v.z);
   }
-  __device__ int hit(int k) const { return P.hit[(size_t)k * P.npix + p]; }
-  __device__ void set_hit(int k, int v) const { P.hit[(size_t)k * P.npix + p] = v; }
-  // origin shared by the record's pending rays + the triangle they leave
-  __device__ void set_origin(jvec3 o, int skip) const {
-    st3(P.org, P.npix, p, o);
-    P.skip[p] = skip;
+  __device__ int hit(int k) const { return reinterpret_cast<const int*>(slot(k))[3]; }
+  __device__ void set_hit(int k, int v) const { reinterpret_cast<int*>(slot(k))[3] = v; }
+  // origin shared by the record's pending rays + the triangle they leave: one float4
+  __device__ void set_origin(jvec3 o, int skip) const { P.orgs[p] = make_float4(o.x, o.y, o.z, __int_as_float(skip)); }
+  __device__ jvec3 origin() const {
+    const float4 v = P.orgs[p];
+    return jv(v.x, v.y, v.z);
   }
+  __device__ int skip() const { return reinterpret_cast<const int*>(P.orgs + p)[3]; }
 };
 
 // The same view held in registers: k_light traces a record's single ray (camera or mirror) in the kernel that shades
@@ -280,8 +281,7 @@ static __device__ bool begin_bounce(const DevScene& S, const Px& px, ShadeCtx& c
       float fresnel_rate_i = R0 + (1 - R0) * one_cosine_i_sqr * one_cosine_i_sqr * one_cosine_i;
       bssrdf = jv_scale(bssrdf, fresnel_rate_i);
 
-      st3(px.P.org, npix, pix, random_point);
-      px.P.skip[pix] = middle;
+      px.set_origin(random_point, middle);
       st3(px.P.aux, npix, pix, bssrdf);
       for (int i = 0; i < nE; ++i) {
         float rx = jade_rand(&c.rng);
@@ -329,8 +329,7 @@ static __device__ bool begin_bounce(const DevScene& S, const Px& px, ShadeCtx& c
       jvec3 refract_ray = gen_refract_ray(rev_out_direction, n, (float)(1.0 / (double)triangle_miu), &full_reflex);
       st3(px.P.aux, npix, pix, jv(1 - fresnel_rate_i, 1 - fresnel_rate_i, 1 - fresnel_rate_i));
       px.P.auxi[pix] = 0;
-      st3(px.P.org, npix, pix, c.src);
-      px.P.skip[pix] = c.obj;
+      px.set_origin(c.src, c.obj);
       px.set_dir(0, refract_ray);
       px.set_hit(0, -1);
       c.n_emit_rays++;
@@ -350,8 +349,7 @@ static __device__ bool begin_bounce(const DevScene& S, const Px& px, ShadeCtx& c
 diffuse_like:
   // ---- diffuse (:1266-1364) and SSS-diffuse (:931-1028): same ray set ----
   {
-    st3(px.P.org, npix, pix, c.src);
-    px.P.skip[pix] = c.obj;
+    px.set_origin(c.src, c.obj);
     const float side = jv_dot(c.out, n);
     for (int i = 0; i < nE; ++i) {
       float rand_x = jade_rand(&c.rng);
@@ -472,7 +470,7 @@ static __device__ int consume(const DevScene& S, const Px& px, ShadeCtx& c, jvec
   }
 
   if (c.stage == ST_BSSRDF) {
-    const int middle = px.P.skip[pix];
+    const int middle = px.skip();
     const jade_triangle* t_i = &T[middle];
     const jvec3 t_norm = V3(t_i->norm);
     const jvec3 bssrdf = ld3(px.P.aux, npix, pix);
@@ -535,7 +533,7 @@ static __device__ int consume(const DevScene& S, const Px& px, ShadeCtx& c, jvec
     const jade_triangle* ht = &T[nh];
     const jvec3 hn = V3(ht->norm);
     jvec3 refract_ray = px.dir(0);
-    jvec3 start = ld3(px.P.org, npix, pix);
+    jvec3 start = px.origin();
     jvec3 hp = px.hpt(0);
     jvec3 l_indir_rate = ld3(px.P.aux, npix, pix);
     bool full_reflex = false;
@@ -555,8 +553,7 @@ static __device__ int consume(const DevScene& S, const Px& px, ShadeCtx& c, jvec
     } else {
       l_indir_rate = jv_scale(l_indir_rate, (float)((1.0 - (double)fresnel_rate_o) * 1.25));
     }
-    st3(px.P.org, npix, pix, hp);
-    px.P.skip[pix] = nh;
+    px.set_origin(hp, nh);
     st3(px.P.aux, npix, pix, l_indir_rate);
     px.P.auxi[pix] = it;
     px.set_dir(0, refract_ray);
