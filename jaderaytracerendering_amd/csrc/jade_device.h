@@ -111,16 +111,15 @@ struct PathState {
   uint32_t* done;       // samples this record has finished
   uint32_t* stage;      // stage | depth << 8 | flags << 16
   float* sum;           // [3][JADE_SAMPLE_LANES * npx] partial radiance sums per (lane, pixel)
-  float* thr;           // [3][npix] throughput (product of pushed rates)
-  float* acc;           // [3][npix] radiance gathered along the current path
-  float* le;            // [3][npix] emission at the primary hit
-  int32_t* obj;         // current vertex: triangle index
-  float* src;           // [3][npix] current vertex position
-  float* out;           // [3][npix] direction back toward the previous vertex
+  // The context of a path in flight, five float4 per record (only k_shade and a record k_light parks touch it; what every
+  // pass of every record reads - rng, done, stage - stays in planes):
+  //   {thr.xyz, obj} {acc.xyz, auxi} {le.xyz, src.x} {src.y, src.z, out.x, out.y} {out.z, aux.xyz}
+  // thr = throughput (product of pushed rates), acc = radiance gathered along the current path, le = emission at the
+  // primary hit, obj = current vertex: triangle index, src = its position, out = direction back toward the previous
+  // vertex, aux = BSSRDF profile / refraction attenuation, auxi = refraction: iteration counter.
+  float4* ctx;
   float eye[3];         // origin of every camera ray (skip == JADE_SKIP_CAMERA): not stored per record
   float4* orgs;         // [npix] {origin shared by this record's pending rays, source triangle of those rays (int bits)}
-  float* aux;           // [3][npix] BSSRDF profile / refraction attenuation
-  int32_t* auxi;        // refraction: iteration counter
   // Ray slots, two float4 per slot and a record's slots side by side: slot[(p * nslots + k) * 2] = {direction, hit (int bits:
   // -2 inactive, -1 queued / miss, >= 0 triangle)}, [.. + 1] = {hit point, HitResult.distance of the best hit as k_trace
   // compared it}.  A ray is one 16-B read and one 32-B sector written for k_trace, and a record's whole bounce (nslots rays

@@ -222,16 +222,18 @@ static __device__ __forceinline__ void shade_record(const DevScene& S, const Pat
       // path_push thr is 1 and acc 0 (only path_push changes them, and it counts depth up); a
       // mirror ray in flight needs neither the vertex it left nor, at depth 0, a stored Le
       // (it is the emissive of the triangle still in obj).
-      c.obj = P.obj[p];
+      const float4* cx = P.ctx + (size_t)p * 5;
+      const float4 b0 = cx[0], b1 = cx[1], b2 = cx[2], b3 = cx[3], b4 = cx[4];
+      c.obj = __float_as_int(b0.w);
       if (c.depth != 0) {
-        c.thr = ld3(P.thr, npix, p);
-        c.acc = ld3(P.acc, npix, p);
+        c.thr = jv(b0.x, b0.y, b0.z);
+        c.acc = jv(b1.x, b1.y, b1.z);
       }
       if (st == ST_MIRROR && c.depth == 0) c.le = V3(S.tris[c.obj].emissive);
-      else c.le = ld3(P.le, npix, p);
+      else c.le = jv(b2.x, b2.y, b2.z);
       if (st != ST_MIRROR) {
-        c.src = ld3(P.src, npix, p);
-        c.out = ld3(P.out, npix, p);
+        c.src = jv(b2.w, b3.x, b3.y);
+        c.out = jv(b3.z, b3.w, b4.x);
       }
     }
     uint32_t done = done0;
@@ -338,16 +340,14 @@ static __device__ __forceinline__ void shade_record(const DevScene& S, const Pat
     P.done[p] = done;
     P.stage[p] = st | (c.depth << 8) | (c.flags << 16);
     if ((st >= ST_DIFFUSE && st <= ST_REFRACT_EXIT) || st == ST_VERTEX) {
-      P.obj[p] = c.obj;
-      if (c.depth != 0) {
-        st3(P.thr, npix, p, c.thr);
-        st3(P.acc, npix, p, c.acc);
-      }
-      if (!(st == ST_MIRROR && c.depth == 0)) st3(P.le, npix, p, c.le);
-      if (st != ST_MIRROR) {
-        st3(P.src, npix, p, c.src);
-        st3(P.out, npix, p, c.out);
-      }
+      // (aux and auxi - words 17-19 and 7 - are begin_bounce's and consume's: written through Px while this record was shaded)
+      float4* cx = P.ctx + (size_t)p * 5;
+      float* cf = reinterpret_cast<float*>(cx);
+      cf[0] = c.thr.x; cf[1] = c.thr.y; cf[2] = c.thr.z; cf[3] = __int_as_float(c.obj);
+      cf[4] = c.acc.x; cf[5] = c.acc.y; cf[6] = c.acc.z;
+      cx[2] = make_float4(c.le.x, c.le.y, c.le.z, c.src.x);
+      cx[3] = make_float4(c.src.y, c.src.z, c.out.x, c.out.y);
+      cf[16] = c.out.z;
     }
   }
   st_out = st;
@@ -976,14 +976,13 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_LIGHT_WAVES) void k_light(De
       P.done[p] = done;
       if (st == ST_VERTEX) {  // parked: the path context, as shade_record stores it for this stage
         P.stage[p] = ST_VERTEX | (c.depth << 8) | (c.flags << 16);
-        P.obj[p] = c.obj;
-        if (c.depth != 0) {
-          st3(P.thr, npix, p, c.thr);
-          st3(P.acc, npix, p, c.acc);
-        }
-        st3(P.le, npix, p, c.le);
-        st3(P.src, npix, p, c.src);
-        st3(P.out, npix, p, c.out);
+        float4* cx = P.ctx + (size_t)p * 5;
+        float* cf = reinterpret_cast<float*>(cx);
+        cf[0] = c.thr.x; cf[1] = c.thr.y; cf[2] = c.thr.z; cf[3] = __int_as_float(c.obj);
+        cf[4] = c.acc.x; cf[5] = c.acc.y; cf[6] = c.acc.z;
+        cx[2] = make_float4(c.le.x, c.le.y, c.le.z, c.src.x);
+        cx[3] = make_float4(c.src.y, c.src.z, c.out.x, c.out.y);
+        cf[16] = c.out.z;
       } else {
         P.stage[p] = ST_IDLE;
       }
@@ -1522,9 +1521,7 @@ static int setup_state(jade_scene* s, int npx, int rpp, int nslots) {
   size_t words = 0;
   auto take = [&](size_t n) { size_t o = words; words += (n + 63) & ~(size_t)63; return o; };
   const size_t N = (size_t)npix, K = (size_t)nslots;
-  size_t o_rng = take(N), o_done = take(N), o_stage = take(N), o_sum = take(3 * (size_t)JADE_SAMPLE_LANES * npx), o_thr = take(3 * N), o_acc = take(3 * N),
-         o_le = take(3 * N), o_obj = take(N), o_src = take(3 * N), o_out = take(3 * N), o_orgs = take(4 * N),
-         o_aux = take(3 * N), o_auxi = take(N), o_slot = take(8 * K * N);
+  size_t o_rng = take(N), o_done = take(N), o_stage = take(N), o_sum = take(3 * (size_t)JADE_SAMPLE_LANES * npx), o_ctx = take(20 * N), o_orgs = take(4 * N), o_slot = take(8 * K * N);
   HIP_TRY(s->b_state.alloc(words * 4));
   HIP_TRY(hipMemsetAsync(s->b_state.p, 0, words * 4, s->stream));
   uint32_t* b = s->b_state.as<uint32_t>();
@@ -1542,9 +1539,7 @@ static int setup_state(jade_scene* s, int npx, int rpp, int nslots) {
   }
   P.nslots = nslots;
   P.rng = b + o_rng; P.done = b + o_done; P.stage = b + o_stage;
-  P.sum = (float*)(b + o_sum); P.thr = (float*)(b + o_thr); P.acc = (float*)(b + o_acc); P.le = (float*)(b + o_le);
-  P.obj = (int32_t*)(b + o_obj); P.src = (float*)(b + o_src); P.out = (float*)(b + o_out); P.orgs = (float4*)(b + o_orgs);
-  P.aux = (float*)(b + o_aux); P.auxi = (int32_t*)(b + o_auxi);
+  P.sum = (float*)(b + o_sum); P.ctx = (float4*)(b + o_ctx); P.orgs = (float4*)(b + o_orgs);
   P.slot = (float4*)(b + o_slot);
   HIP_TRY(s->b_queue.alloc(K * N * 4));
   // b_active[0] doubles as k_light's per-wave hand-over regions: up to 64 records of slack per wave of its grid

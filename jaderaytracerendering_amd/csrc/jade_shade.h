@@ -131,6 +131,17 @@ struct Px {
     return jv(v.x, v.y, v.z);
   }
   __device__ int skip() const { return reinterpret_cast<const int*>(P.orgs + p)[3]; }
+  // aux / auxi of the path context (jade_device.h): words 17-19 and 7 of the record's five float4
+  __device__ jvec3 aux() const {
+    const float* f = reinterpret_cast<const float*>(P.ctx + (size_t)p * 5);
+    return jv(f[17], f[18], f[19]);
+  }
+  __device__ void set_aux(jvec3 v) const {
+    float* f = reinterpret_cast<float*>(P.ctx + (size_t)p * 5);
+    f[17] = v.x; f[18] = v.y; f[19] = v.z;
+  }
+  __device__ int auxi() const { return reinterpret_cast<const int*>(P.ctx + (size_t)p * 5)[7]; }
+  __device__ void set_auxi(int v) const { reinterpret_cast<int*>(P.ctx + (size_t)p * 5)[7] = v; }
 };
 
 // The same view held in registers: k_light traces a record's single ray (camera or mirror) in the kernel that shades
@@ -234,8 +245,6 @@ static __device__ bool begin_bounce(const DevScene& S, const Px& px, ShadeCtx& c
   *l_final = jv(0, 0, 0);
   const jvec3 n = V3(ot->norm);
   float select_reflex_refract = jade_rand(&c.rng);
-  const int pix = px.p;
-  const int npix = px.P.npix;
   if (select_reflex_refract < 0.5f && ot->refract_mode != JADE_NO_REFRACT) {
     if (ot->refract_mode == JADE_SUB_SURFACE) {
       select_reflex_refract = jade_rand(&c.rng);
@@ -282,7 +291,7 @@ static __device__ bool begin_bounce(const DevScene& S, const Px& px, ShadeCtx& c
       bssrdf = jv_scale(bssrdf, fresnel_rate_i);
 
       px.set_origin(random_point, middle);
-      st3(px.P.aux, npix, pix, bssrdf);
+      px.set_aux(bssrdf);
       for (int i = 0; i < nE; ++i) {
         float rx = jade_rand(&c.rng);
         float ry = jade_rand(&c.rng);
@@ -327,8 +336,8 @@ static __device__ bool begin_bounce(const DevScene& S, const Px& px, ShadeCtx& c
       bool full_reflex = false;
       jvec3 rev_out_direction = jv_scale(c.out, -1.0f);
       jvec3 refract_ray = gen_refract_ray(rev_out_direction, n, (float)(1.0 / (double)triangle_miu), &full_reflex);
-      st3(px.P.aux, npix, pix, jv(1 - fresnel_rate_i, 1 - fresnel_rate_i, 1 - fresnel_rate_i));
-      px.P.auxi[pix] = 0;
+      px.set_aux(jv(1 - fresnel_rate_i, 1 - fresnel_rate_i, 1 - fresnel_rate_i));
+      px.set_auxi(0);
       px.set_origin(c.src, c.obj);
       px.set_dir(0, refract_ray);
       px.set_hit(0, -1);
@@ -422,7 +431,6 @@ static __device__ int consume(const DevScene& S, const Px& px, ShadeCtx& c, jvec
   const int nE = S.n_emit;
   const float PI_F = (float)JADE_PI_D;
   const float RR_F = (float)JADE_RR_RATE_D;
-  const int pix = px.p, npix = px.P.npix;
   const jade_triangle* ot = &T[c.obj];
   const jvec3 n = V3(ot->norm);
   const int k = ot->refract_mode != JADE_NO_REFRACT ? 2 : 1;
@@ -473,7 +481,7 @@ static __device__ int consume(const DevScene& S, const Px& px, ShadeCtx& c, jvec
     const int middle = px.skip();
     const jade_triangle* t_i = &T[middle];
     const jvec3 t_norm = V3(t_i->norm);
-    const jvec3 bssrdf = ld3(px.P.aux, npix, pix);
+    const jvec3 bssrdf = px.aux();
     const float eta = t_i->refract_index;
     const float R0 = (eta - 1) / (eta + 1) * (eta - 1) / (eta + 1);
     const float area_total = S.prefix[S.segs[t_i->obj_idx].end_idx];
@@ -535,7 +543,7 @@ static __device__ int consume(const DevScene& S, const Px& px, ShadeCtx& c, jvec
     jvec3 refract_ray = px.dir(0);
     jvec3 start = px.origin();
     jvec3 hp = px.hpt(0);
-    jvec3 l_indir_rate = ld3(px.P.aux, npix, pix);
+    jvec3 l_indir_rate = px.aux();
     bool full_reflex = false;
     refract_ray = gen_refract_ray(refract_ray, hn, triangle_miu, &full_reflex);
     jvec3 distance = jv_sub(start, hp);
@@ -544,7 +552,7 @@ static __device__ int consume(const DevScene& S, const Px& px, ShadeCtx& c, jvec
                                            jade_powf(ht->refract_rate[2], dist)));
     float fresnel_rate_o = schlick_out(R0, jade_fabs(jv_dot(refract_ray, hn)));
     float reflex_refract_select = jade_rand(&c.rng);
-    int it = px.P.auxi[pix] + 1;
+    int it = px.auxi() + 1;
     bool leave = true;
     if (full_reflex || reflex_refract_select < 0.2f) {
       refract_ray = jv_sub(refract_ray, jv_scale(hn, 2 * jv_dot(refract_ray, hn)));
@@ -554,8 +562,8 @@ static __device__ int consume(const DevScene& S, const Px& px, ShadeCtx& c, jvec
       l_indir_rate = jv_scale(l_indir_rate, (float)((1.0 - (double)fresnel_rate_o) * 1.25));
     }
     px.set_origin(hp, nh);
-    st3(px.P.aux, npix, pix, l_indir_rate);
-    px.P.auxi[pix] = it;
+    px.set_aux(l_indir_rate);
+    px.set_auxi(it);
     px.set_dir(0, refract_ray);
     px.set_hit(0, -1);
     *l_final = jv(0, 0, 0);
@@ -573,7 +581,7 @@ static __device__ int consume(const DevScene& S, const Px& px, ShadeCtx& c, jvec
   // ST_REFRACT_EXIT, PathTrace.cu:1239-1257
   {
     jvec3 refract_ray = px.dir(0);
-    jvec3 l_indir_rate = ld3(px.P.aux, npix, pix);
+    jvec3 l_indir_rate = px.aux();
     float kk = (float)(k / JADE_RR_RATE_D);
     int nh = px.hit(0);
     if (nh >= 0) {
