@@ -18,13 +18,16 @@ the K steps — `samples` = K * spp * pixels, and all their rays — is computed
 
 value = (primary + secondary rays traced by all ranks in the K timed steps) / max-over-ranks wall time, Mray/s.
         A ray = one hitBVH query (PathTrace.cu:795).
-roofline: the dominant kernel, k_trace (BVH traversal + triangle tests), against the roof that BINDS it: VALU
-        issue.  achieved = VALU lane-operations per second = (lane-ops per ray, SQ_THREAD_CYCLES_VALU from the
-        rocprofv3 --pmc pass of this same command, profiles/valu_issue.json) x (rays this run traced) / (k_trace
-        time of this run, HIP events on the kernel's own stream); peak = 1024 SIMDs x 32 lanes per clock x 2.4 GHz
-        (see VALU_PEAK_TLANEOPS).  frac = (lanes active per VALU instruction / 64) x (VALU instructions issued per SIMD
-        per 2 clocks) x (clock held / 2.4 GHz), <= 1.  `binding` names the roof that is nearer for this configuration:
-        VALU issue on C3 (scene L2-resident), HBM on C5 (873k triangles: 49 % L2 hits, 5.4 TB/s of HBM traffic).
+roofline: the dominant kernel, k_trace (BVH traversal + triangle tests), against the arithmetic roof of a kernel
+        without matrix work: VALU issue.  achieved = VALU lane-operations per second = (lane-ops per ray,
+        SQ_THREAD_CYCLES_VALU from the rocprofv3 --pmc pass of this same command, profiles/valu_issue.json) x (rays
+        this run traced) / (k_trace time of this run, HIP events on the kernel's own stream); peak = 1024 SIMDs x 32
+        lanes per clock x 2.4 GHz (see VALU_PEAK_TLANEOPS).  frac = (lanes active per VALU instruction / 64) x (VALU
+        instructions issued per SIMD per 2 clocks) x (clock held / 2.4 GHz), <= 1.  `binding` says what limits the
+        kernel on this configuration: on C3 (scene L2-resident) NO unit is saturated since the wave-wide leaf queue cut
+        the instructions per ray by a third - the kernel is bound by the latency of a ray's chain of dependent node
+        visits (`sensitivity` carries the ablations, profiles/sensitivity_r02.json); on C5 (873k
+        triangles: 51 % L2 hits, 5.9 TB/s) it is HBM.
 roofline_hbm: the HBM view SURVEY.md 8d prices the path with.  achieved = MEASURED HBM bytes (PMC FETCH_SIZE x 2 +
         WRITE_SIZE per ray, profiles/hbm_traffic.json) x rays / k_trace time, against 8 TB/s; `algorithmic_GBps` is
         the reference traversal's 40 B per node record + 36 B per triangle test delivered per second — it exceeds
@@ -49,9 +52,9 @@ HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # VALU issue roof (MI355X_MICROARCH.md: 4 SIMD-32 per CU, a wave64 VALU instruction issues in 2 clocks): 32 lane-operations per
 # clock per SIMD.  That rate needs instructions the sequencer can pair (SQ_ACTIVE_INST_VALU2); a wave's own dependent stream issues
 # one per 4 clocks, which is the unit SQ_ACTIVE_INST_VALU counts in (1.007 quad-cycles per VALU instruction in every kernel
-# here).  k_trace's time follows its VALU instruction count (ablations) and its SIMDs show 4 x ACTIVE_INST_VALU
-# / SIMD-cycles = 1.05 of a possible 2: the roofline below is priced against the full 2-clock rate, `issue_busy_of_2` says how
-# far the issue side is from it.
+# here).  The first k_trace of round 2 sat at 4 x ACTIVE_INST_VALU / SIMD-cycles = 1.05 of a possible 2 and its time followed
+# its instruction count; the final one issues a third fewer instructions and sits at 0.7.  The roofline below
+# is priced against the full 2-clock rate, `issue_busy_of_2` says how far the issue side is from it.
 VALU_PEAK_TLANEOPS = 1024 * 32 * 2.4e9 / 1e12  # 256 CUs x 4 SIMDs x 32 lanes, 2.4 GHz = 78.6 T lane-ops/s
 
 
@@ -279,8 +282,15 @@ def main():
             "nodes_per_ray": float(vals[1].item()) / rays_all, "tris_per_ray": float(vals[2].item()) / rays_all,
             "roofline": roof,
             "roofline_hbm": roof_hbm,
-            "binding": None if roof["frac"] is None or roof_hbm["frac"] is None else ("hbm" if roof_hbm["frac"] > roof["frac"] else "valu"),
+            # HBM when the measured traffic is the larger share of its roof; otherwise neither roof binds
+            "binding": None if roof["frac"] is None or roof_hbm["frac"] is None else
+                       ("hbm" if roof_hbm["frac"] > roof["frac"] else "latency (no unit saturated: VALU issue %.2f of 2, HBM %.0f %% of peak)"
+                        % (roof.get("issue_busy_of_2") or 0.0, 100.0 * roof_hbm["frac"])),
         }
+        sens = profile_json("sensitivity_r02.json")
+        if sens and key == "C3":
+            out["sensitivity"] = {"source": "profiles/sensitivity_r02.json", "k_trace_ms_per_256spp_step": sens.get("ablations_k_trace_ms_per_256spp_step"),
+                                  "reading": sens.get("reading")}
         if world == 1 and part_world == 1 and not args.no_extras and args.config in ("C2", "C3", "C4"):
             out["statue_closeup"] = closeup(scene, hip, B, H, _abi, cfg, width, height, args.spp_per_step)
         if world == 1 and not args.no_cpu_baseline:

@@ -476,7 +476,6 @@ __global__ __launch_bounds__(JADE_LEAN_BLOCK) void k_shade_lean(DevScene S, Path
 }
 
 #define JADE_CTL_RING 16 /* QueueCtl records: entry 0 for passes the host follows one by one, all of them for a batch of passes */
-#define JADE_CTX_WORDS (JADE_LDS_STACK + JADE_LDS_FIFO + JADE_LDS_STATE) /* LDS words per lane */
 #ifndef JADE_TRACE_NT
 #define JADE_TRACE_NT 1 /* k_trace reads and writes the ray records with non-temporal hints */
 #endif
@@ -496,18 +495,6 @@ static __device__ __forceinline__ void nt_st4(float4* p, float x, float y, float
   const jade_v4f v = {x, y, z, w};
   NT_ST(reinterpret_cast<jade_v4f*>(p), v);
 }
-#ifndef JADE_TRACE_PROFILE
-#define JADE_TRACE_PROFILE 0
-#endif
-#ifndef JADE_STEPS_PER_PICK
-#define JADE_STEPS_PER_PICK 4 /* units of the picked kind per wave iteration (k_trace per 256-spp step, packed build: 2: 282, 3: 275, 4: 273 ms) */
-#endif
-#ifndef JADE_COST_NODE
-#define JADE_COST_NODE 100 /* instructions issued by a node-walk iteration ... */
-#endif
-#ifndef JADE_COST_TRI
-#define JADE_COST_TRI 120  /* ... and by a triangle-test iteration (k_trace picks the kind per wave iteration) */
-#endif
 #ifndef JADE_TRACE_WAVES
 #define JADE_TRACE_WAVES 4 /* waves per SIMD the register allocation leaves room for: k_trace's LDS (34 KB per block) admits 4 blocks per CU; 4 and 5 blocks run at the same speed (the kernel is bound by latency and by L2 line fetches, not by issue: DESIGN.md 3.4) */
 #endif
@@ -542,9 +529,6 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
   }
   uint32_t V = 0, T = 0;  // wave totals (uniform: they live in SGPRs)
   uint32_t vcnt = 0, tcnt = 0;  // per lane, summed over the wave once at the end (a ballot + popcount per unit was 8 instructions)
-#if JADE_TRACE_PROFILE
-  uint32_t prof_units = 0, prof_lanes = 0;  // development: units run of one kind (1 node, 2 triangle, 3 any) and lanes that took part
-#endif
   // wave-local chunk of the queue: [lbase, lend) (wave-uniform)
   uint32_t lbase = 0, lend = 0;
   bool queue_empty = false;
@@ -557,36 +541,11 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
   r.cur = JADE_REF_NONE;
   r.sp = stk.col;
   r.pushed = 0;
-  // the wave's ring of leaves to test: q_count items from q_head on (wave-uniform), and the item this lane is testing
-  const uint32_t wq = lds_addr_of(&lds_wq[threadIdx.x >> 6][0]);
-  const uint32_t hq = lds_addr_of(&lds_hq[threadIdx.x >> 6][0]);
-  uint32_t q_head = 0, q_count = 0, h_head = 0, h_count = 0;
-  uint32_t item_leaf = 0, item_meta = 0;
-  const uint32_t lane_below_lo = lane < 32 ? (1u << lane) - 1u : 0xffffffffu, lane_below_hi = lane < 32 ? 0u : (1u << (lane - 32)) - 1u;
-  auto rank_in = [&](unsigned long long m) -> uint32_t {  // lanes of m below this one
-    return (uint32_t)__popc((uint32_t)m & lane_below_lo) + (uint32_t)__popc((uint32_t)(m >> 32) & lane_below_hi);
-  };
-  // resolve up to 64 of the waiting candidates, one per lane (jade_trace.h)
-  auto resolve_pass = [&]() {
-    const uint32_t nres = h_count < 64u ? h_count : 64u;
-    const bool mine = (uint32_t)lane < nres;
-    uint32_t ref = 0, meta = 0;
-    if (mine) lds_ld64(hq + ((h_head + (uint32_t)lane) & (JADE_HQ - 1u)) * 8u, ref, meta);
-    h_head = (h_head + nres) & (JADE_HQ - 1u);
-    h_count -= nres;
-    const int owner = (int)(meta & 63u);
-    RayOD od;
-    od.a.x = __shfl(r.od.a.x, owner, 64);
-    od.a.y = __shfl(r.od.a.y, owner, 64);
-    od.b.x = __shfl(r.od.b.x, owner, 64);
-    od.b.y = __shfl(r.od.b.y, owner, 64);
-    od.c.x = __shfl(r.od.c.x, owner, 64);
-    od.c.y = __shfl(r.od.c.y, owner, 64);
-    if (mine) resolve_hit(ref, meta, od, S, stk, lane);
-  };
+  WaveTrace wt;  // the wave's rings of leaves to test and of hit candidates, and the item this lane is testing (jade_trace.h)
+  wt.init(lds_addr_of(&lds_wq[threadIdx.x >> 6][0]), lds_addr_of(&lds_hq[threadIdx.x >> 6][0]), lane);
   for (;;) {
     // ---- a ray has ended when its walk has and all the leaves it pushed have been finished
-    if (active && r.cur == JADE_REF_NONE && lds_ld_v(stk.col + TW_FINISHED * JADE_COL_STRIDE) == r.pushed) {
+    if (active && WaveTrace::ray_ended(r, stk)) {
       active = false;
       wb = true;
     }
@@ -622,7 +581,7 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
         }
         const uint32_t avail = lend - lbase;
         const uint32_t take = (uint32_t)n_idle < avail ? (uint32_t)n_idle : avail;
-        const uint32_t rank = rank_in(idle);
+        const uint32_t rank = wt.rank_in(idle);
         if (!active && rank < take) {
           my_e = NT_LD(&queue[lbase + rank]);
           const uint32_t p = my_e / (uint32_t)P.nslots;  // the entry is the slot number p * nslots + k
@@ -639,113 +598,13 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
       }
     }
     if (n_idle == 64 && queue_empty) break;  // nothing in flight (so no leaf is waiting either), nothing left to claim
-    // ---- one kind of work per iteration: the walk, for the lanes whose ray still walks, or triangle tests, for as many
-    // lanes as there are leaves waiting.  The kind that advances more lanes per instruction issued runs; the walk needs
-    // room for the 64 leaves one unit of it can push.
-    const int nw = __popcll(__ballot(active && r.cur != JADE_REF_NONE));
-    const uint32_t n_items = q_count + (uint32_t)__popcll(__ballot(item_leaf != 0));
-    const uint32_t nt = n_items < 64u ? n_items : 64u;
-    if (nw == 0 && n_items == 0) {  // every ray in flight waits for candidates (fewer than a batch): resolve them now
-      if (h_count != 0) resolve_pass();
-      continue;
-    }
-    if (q_count <= JADE_WQ - 64 && nw > 0 && JADE_COST_TRI * (uint32_t)nw >= JADE_COST_NODE * nt) {
-      const bool general = S.general_walk || __ballot(active && (int32_t)r.skipx < 0) != 0ull;  // per WAVE (jade_trace.h)
-#pragma nounroll
-      for (int rep = 0; rep < JADE_STEPS_PER_PICK; ++rep) {
-        if (q_count > JADE_WQ - 64) break;
-        const bool go = active && r.cur != JADE_REF_NONE;
-#if JADE_TRACE_PROFILE == 1
-        prof_units += 1;
-        prof_lanes += (uint32_t)__popcll(__ballot(go));
-#endif
-#if JADE_TRACE_PROFILE == 4  /* node visits, and how many of them fall on the JADE_PROF_TOPK largest nodes */
-        prof_units += (uint32_t)__popcll(__ballot(go && (int32_t)r.cur >= 0));
-        prof_lanes += (uint32_t)__popcll(__ballot(go && r.cur < JADE_PROF_TOPK));
-#endif
-        uint32_t leafv = 0;
-        if (general) {
-          if (go) leafv = walk_step<true>(r, S, stk, vcnt);
-        } else {
-          if (go) leafv = walk_step<false>(r, S, stk, vcnt);
-        }
-        // the leaves met by this unit, in lane order (any order would do: a leaf's place among its ray's leaves is its
-        // sequence number)
-        const unsigned long long m = __ballot(leafv != 0);
-        if (m != 0ull) {
-          if (leafv != 0) {
-            const uint32_t slot = (q_head + q_count + rank_in(m)) & (JADE_WQ - 1u);
-            lds_st64(wq + slot * 8u, leafv, (uint32_t)lane | (r.pushed << 6));
-            r.pushed += 1u;
-          }
-          q_count += (uint32_t)__popcll(m);
-        }
-      }
-    } else {
-#pragma nounroll
-      for (int rep = 0; rep < JADE_STEPS_PER_PICK; ++rep) {
-        // lanes without an item take the next ones from the ring
-        const unsigned long long need = __ballot(item_leaf == 0);
-        if (q_count != 0 && need != 0ull) {
-          const uint32_t rk = rank_in(need);
-          if (item_leaf == 0 && rk < q_count) {
-            lds_ld64(wq + ((q_head + rk) & (JADE_WQ - 1u)) * 8u, item_leaf, item_meta);
-          }
-          const uint32_t want = (uint32_t)__popcll(need);
-          const uint32_t npop = want < q_count ? want : q_count;
-          q_head = (q_head + npop) & (JADE_WQ - 1u);
-          q_count -= npop;
-        }
-        const bool go = item_leaf != 0;
-        if (__ballot(go) == 0ull) break;
-#if JADE_TRACE_PROFILE == 2
-        prof_units += 1;
-        prof_lanes += (uint32_t)__popcll(__ballot(go));
-#endif
-        // the record first (it depends on the item alone), then the ray the item belongs to: seven registers of the lane that
-        // walks it (every lane executes the reads: ds_bpermute returns 0 for a source lane that is masked off)
-        const uint32_t off = item_leaf & 0x7ffffff0u;
-        PairRec rec;
-        if (go) rec = pair_load(S, off);
-        const int owner = (int)(item_meta & 63u);
-        RayOD od;
-        od.a.x = __shfl(r.od.a.x, owner, 64);
-        od.a.y = __shfl(r.od.a.y, owner, 64);
-        od.b.x = __shfl(r.od.b.x, owner, 64);
-        od.b.y = __shfl(r.od.b.y, owner, 64);
-        od.c.x = __shfl(r.od.c.x, owner, 64);
-        od.c.y = __shfl(r.od.c.y, owner, 64);
-        const uint32_t skip = (uint32_t)__shfl((int)r.skipx, owner, 64) & 0x7fffffffu;
-        bool in_a = false, in_b = false;
-        if (go) test_step(item_leaf, item_meta, od, skip, rec, stk, lane, tcnt, in_a, in_b);
-        // candidates (the origin projects into the triangle) are resolved later, many at a time
-        const unsigned long long ma = __ballot(in_a), mb = __ballot(in_b);
-        if (ma != 0ull) {
-          if (h_count > JADE_HQ - 64) resolve_pass();
-          if (in_a) lds_st64(hq + ((h_head + h_count + rank_in(ma)) & (JADE_HQ - 1u)) * 8u, off, item_meta);
-          h_count += (uint32_t)__popcll(ma);
-        }
-        if (mb != 0ull) {
-          if (h_count > JADE_HQ - 64) resolve_pass();
-          if (in_b) lds_st64(hq + ((h_head + h_count + rank_in(mb)) & (JADE_HQ - 1u)) * 8u, off | 1u, item_meta);
-          h_count += (uint32_t)__popcll(mb);
-        }
-      }
-      if (h_count >= JADE_HQ_BATCH) resolve_pass();
-    }
-#if JADE_TRACE_PROFILE == 3
-    prof_units += 1;
-    prof_lanes += (uint32_t)__popcll(__ballot(active));
-#endif
+    // ---- one iteration of work for the wave: walk units, test units or a pass over the hit candidates (jade_trace.h)
+    wt.iterate(r, active, S, stk, vcnt, tcnt);
   }
   V += (uint32_t)wave_sum_u32(vcnt);  // (valid in lane 0, the only lane that uses it)
   T += (uint32_t)wave_sum_u32(tcnt);
   if (lane == 0) {
     DevCounters* cs = ctr + (blockIdx.x % JADE_CTR_SHARDS);
-#if JADE_TRACE_PROFILE
-    atomicAdd(&cs->pad[0], (unsigned long long)prof_units);
-    atomicAdd(&cs->pad[1], (unsigned long long)prof_lanes);
-#endif
     if (V) atomicAdd(&cs->nodes_visited, (unsigned long long)V);
     if (T) atomicAdd(&cs->tris_tested, (unsigned long long)T);
   }
@@ -773,7 +632,7 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
 __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_LIGHT_WAVES) void k_light(DevScene S, PathState P, RenderConst R, const int32_t* tile_ids,
                                                                             uint32_t target_spp, uint32_t* heavy_regions, uint32_t region_cap,
                                                                             uint32_t* wave_counts, uint32_t* spill, DevCounters* ctr) {
-  __shared__ __attribute__((aligned(JADE_COLS_ALIGN))) uint32_t lds_cols[JADE_CTX_WORDS * JADE_TRACE_BLOCK];
+  __shared__ __attribute__((aligned(JADE_COLS_ALIGN))) uint32_t lds_cols[LW_END * JADE_TRACE_BLOCK];
   __shared__ uint32_t sh_ctr[JADE_TRACE_BLOCK / 64][8];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   LdsStack stk;
@@ -948,7 +807,9 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_LIGHT_WAVES) void k_light(De
         }
         if (__ballot(active) == 0ull) continue;  // (every lane went out or parked: the loop ends at its top)
       }
-      // ---- one kind of work for every tracing lane that has some (k_trace's inner loop: hitBVH, PathTrace.cu:795-859)
+      // ---- one kind of work for every tracing lane that has some (hitBVH, PathTrace.cu:795-859).  The lane tests the leaves
+      // of its own ray here (a FIFO per lane, jade_trace.h): camera and floor-mirror rays of neighbouring pixels are short and
+      // walk side by side, and k_trace's wave-wide queue of leaves costs this kernel more than it saves (282 vs 238 ms per step)
       {
         const bool cw = active && ray_can_walk(r), ct = active && ray_can_test(r);
         const int nw = __popcll(__ballot(cw)), nt = __popcll(__ballot(ct));
@@ -1645,10 +1506,6 @@ static hipError_t sum_counters(jade_scene* s, DevCounters* out) {
     out->rays_inline += c.rays_inline;
     out->pad[0] += c.pad[0]; out->pad[1] += c.pad[1];
   }
-#if JADE_TRACE_PROFILE
-  fprintf(stderr, "[jade] k_trace profile %d: %llu units, %.1f lanes per unit\n", JADE_TRACE_PROFILE, out->pad[0],
-          out->pad[0] ? (double)out->pad[1] / (double)out->pad[0] : 0.0);
-#endif
   return e;
 }
 

@@ -628,3 +628,142 @@ static __device__ __forceinline__ int32_t walk_result(const LdsStack& stk, const
   pair_hit(t0, k, od, &d2, P);
   return (int32_t)(jade_f2u(t0[4].z) + (uint32_t)k);
 }
+
+// JADE_COST_NODE / JADE_COST_TRI: instructions issued by a walk unit / a test unit (the kind that advances more lanes
+// per instruction issued runs); JADE_STEPS_PER_PICK: units of the picked kind per wave iteration.
+#ifndef JADE_STEPS_PER_PICK
+#define JADE_STEPS_PER_PICK 4
+#endif
+#ifndef JADE_COST_NODE
+#define JADE_COST_NODE 100
+#endif
+#ifndef JADE_COST_TRI
+#define JADE_COST_TRI 120
+#endif
+
+// A wave's side of the scheme above: its two rings, the item each lane is testing, and one iteration of work.  Used by
+// k_trace (rays from the queue) and k_light (rays from the lane's own path): everything in here is wave-uniform control
+// flow around the per-lane steps.
+struct WaveTrace {
+  uint32_t wq, hq;               // LDS byte addresses of the ring of leaves and of the ring of candidates
+  uint32_t q_head, q_count;      // leaves waiting (wave-uniform)
+  uint32_t h_head, h_count;      // candidates waiting (wave-uniform)
+  uint32_t item_leaf, item_meta; // the leaf this lane is testing (cursor, 0 = none) and its owner | sequence << 6
+  uint32_t below_lo, below_hi;   // the lanes below this one, as two 32-bit masks
+  int lane;
+
+  __device__ __forceinline__ void init(uint32_t wq_addr, uint32_t hq_addr, int lane_) {
+    wq = wq_addr;
+    hq = hq_addr;
+    q_head = q_count = h_head = h_count = 0;
+    item_leaf = item_meta = 0;
+    lane = lane_;
+    below_lo = lane_ < 32 ? (1u << lane_) - 1u : 0xffffffffu;
+    below_hi = lane_ < 32 ? 0u : (1u << (lane_ - 32)) - 1u;
+  }
+  __device__ __forceinline__ uint32_t rank_in(unsigned long long m) const {  // lanes of m below this one
+    return (uint32_t)__popc((uint32_t)m & below_lo) + (uint32_t)__popc((uint32_t)(m >> 32) & below_hi);
+  }
+  // the ray of lane `owner`: six registers of that lane (every lane must execute this: ds_bpermute returns 0 for a source
+  // lane that is masked off)
+  static __device__ __forceinline__ RayOD ray_of(const WalkState& r, int owner) {
+    RayOD od;
+    od.a.x = __shfl(r.od.a.x, owner, 64);
+    od.a.y = __shfl(r.od.a.y, owner, 64);
+    od.b.x = __shfl(r.od.b.x, owner, 64);
+    od.b.y = __shfl(r.od.b.y, owner, 64);
+    od.c.x = __shfl(r.od.c.x, owner, 64);
+    od.c.y = __shfl(r.od.c.y, owner, 64);
+    return od;
+  }
+  // resolve up to 64 of the waiting candidates, one per lane
+  __device__ __forceinline__ void resolve_pass(const WalkState& r, const DevScene& S, const LdsStack& stk) {
+    const uint32_t nres = h_count < 64u ? h_count : 64u;
+    const bool mine = (uint32_t)lane < nres;
+    uint32_t ref = 0, meta = 0;
+    if (mine) lds_ld64(hq + ((h_head + (uint32_t)lane) & (JADE_HQ - 1u)) * 8u, ref, meta);
+    h_head = (h_head + nres) & (JADE_HQ - 1u);
+    h_count -= nres;
+    const RayOD od = ray_of(r, (int)(meta & 63u));
+    if (mine) resolve_hit(ref, meta, od, S, stk, lane);
+  }
+  // a lane's ray has ended: its walk has, and every leaf it pushed has been finished (candidates included)
+  static __device__ __forceinline__ bool ray_ended(const WalkState& r, const LdsStack& stk) {
+    return r.cur == JADE_REF_NONE && lds_ld_v(stk.col + TW_FINISHED * JADE_COL_STRIDE) == r.pushed;
+  }
+  // One iteration: one kind of work for the wave - the walk, for the lanes whose ray still walks (`active`: this lane
+  // holds a ray), or triangle tests, for as many lanes as there are leaves waiting.  The kind that advances more lanes per
+  // instruction issued runs; the walk needs room for the 64 leaves one unit of it can push.  When every ray in flight only
+  // waits for candidates (fewer than a batch), they are resolved.
+  __device__ __forceinline__ void iterate(WalkState& r, bool active, const DevScene& S, const LdsStack& stk, uint32_t& vcnt, uint32_t& tcnt) {
+    const int nw = __popcll(__ballot(active && r.cur != JADE_REF_NONE));
+    const uint32_t n_items = q_count + (uint32_t)__popcll(__ballot(item_leaf != 0));
+    const uint32_t nt = n_items < 64u ? n_items : 64u;
+    if (nw == 0 && n_items == 0) {
+      if (h_count != 0) resolve_pass(r, S, stk);
+      return;
+    }
+    if (q_count <= JADE_WQ - 64 && nw > 0 && JADE_COST_TRI * (uint32_t)nw >= JADE_COST_NODE * nt) {
+      const bool general = S.general_walk || __ballot(active && (int32_t)r.skipx < 0) != 0ull;  // per WAVE (node_core)
+#pragma nounroll
+      for (int rep = 0; rep < JADE_STEPS_PER_PICK; ++rep) {
+        if (q_count > JADE_WQ - 64) break;
+        const bool go = active && r.cur != JADE_REF_NONE;
+        uint32_t leafv = 0;
+        if (general) {
+          if (go) leafv = walk_step<true>(r, S, stk, vcnt);
+        } else {
+          if (go) leafv = walk_step<false>(r, S, stk, vcnt);
+        }
+        // the leaves met by this unit, in lane order (any order would do: a leaf's place among its ray's leaves is its
+        // sequence number)
+        const unsigned long long m = __ballot(leafv != 0);
+        if (m != 0ull) {
+          if (leafv != 0) {
+            lds_st64(wq + ((q_head + q_count + rank_in(m)) & (JADE_WQ - 1u)) * 8u, leafv, (uint32_t)lane | (r.pushed << 6));
+            r.pushed += 1u;
+          }
+          q_count += (uint32_t)__popcll(m);
+        }
+      }
+    } else {
+#pragma nounroll
+      for (int rep = 0; rep < JADE_STEPS_PER_PICK; ++rep) {
+        // lanes without an item take the next ones from the ring
+        const unsigned long long need = __ballot(item_leaf == 0);
+        if (q_count != 0 && need != 0ull) {
+          const uint32_t rk = rank_in(need);
+          if (item_leaf == 0 && rk < q_count) lds_ld64(wq + ((q_head + rk) & (JADE_WQ - 1u)) * 8u, item_leaf, item_meta);
+          const uint32_t want = (uint32_t)__popcll(need);
+          const uint32_t npop = want < q_count ? want : q_count;
+          q_head = (q_head + npop) & (JADE_WQ - 1u);
+          q_count -= npop;
+        }
+        const bool go = item_leaf != 0;
+        if (__ballot(go) == 0ull) break;
+        // the record first (it depends on the item alone), then the ray the item belongs to
+        const uint32_t off = item_leaf & 0x7ffffff0u;
+        PairRec rec;
+        if (go) rec = pair_load(S, off);
+        const int owner = (int)(item_meta & 63u);
+        const RayOD od = ray_of(r, owner);
+        const uint32_t skip = (uint32_t)__shfl((int)r.skipx, owner, 64) & 0x7fffffffu;
+        bool in_a = false, in_b = false;
+        if (go) test_step(item_leaf, item_meta, od, skip, rec, stk, lane, tcnt, in_a, in_b);
+        // candidates (the origin projects into the triangle) are resolved later, many at a time
+        const unsigned long long ma = __ballot(in_a), mb = __ballot(in_b);
+        if (ma != 0ull) {
+          if (h_count > JADE_HQ - 64) resolve_pass(r, S, stk);
+          if (in_a) lds_st64(hq + ((h_head + h_count + rank_in(ma)) & (JADE_HQ - 1u)) * 8u, off, item_meta);
+          h_count += (uint32_t)__popcll(ma);
+        }
+        if (mb != 0ull) {
+          if (h_count > JADE_HQ - 64) resolve_pass(r, S, stk);
+          if (in_b) lds_st64(hq + ((h_head + h_count + rank_in(mb)) & (JADE_HQ - 1u)) * 8u, off | 1u, item_meta);
+          h_count += (uint32_t)__popcll(mb);
+        }
+      }
+      if (h_count >= JADE_HQ_BATCH) resolve_pass(r, S, stk);
+    }
+  }
+};
