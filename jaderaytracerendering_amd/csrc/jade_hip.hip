@@ -1543,7 +1543,7 @@ static int run_passes(jade_scene* s, uint32_t target_spp, bool may_carry, double
   bool have_list = true;  // b_active[cur] lists the active records
   bool light_timed = false;
   float shade_ms = 0, lean_ms = 0;
-  static const double carry_frac = getenv("JADE_CARRY_FRACTION") ? atof(getenv("JADE_CARRY_FRACTION")) : JADE_CARRY_FRACTION;
+  const double carry_frac = getenv("JADE_CARRY_FRACTION") ? atof(getenv("JADE_CARRY_FRACTION")) : JADE_CARRY_FRACTION;
   auto carry_now = [&](uint32_t act) {
     return may_carry && ((act < JADE_CARRY_RECORDS && (uint64_t)act * 1024 < (uint64_t)n_armed) ||
                          (carry_frac > 0 && (double)act < carry_frac * (double)n_armed));
@@ -1782,7 +1782,7 @@ int jade_render_step(jade_scene* s, int32_t spp, jade_stats* st) {
   HIP_TRY(hipSetDevice(s->device));
   s->spp_done += spp;
   if (s->ps.npix == 0 || spp == 0) return JADE_OK;
-  static const bool carry = !(getenv("JADE_CARRY") && atoi(getenv("JADE_CARRY")) == 0);
+  const bool carry = !(getenv("JADE_CARRY") && atoi(getenv("JADE_CARRY")) == 0);
   return advance(s, s->spp_done - spp, carry, st);
 }
 
