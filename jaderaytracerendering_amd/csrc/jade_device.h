@@ -30,7 +30,7 @@
 
 #define JADE_REF_LEAF 0x80000000u
 #define JADE_REF_NONE 0x7fffffffu
-#define JADE_MAX_TRIS ((1 << 27) / 3) /* leaf refs carry 48 * first_triangle in bits 4-30 (jade_trace.h) */
+#define JADE_MAX_TRIS ((1 << 27) / 3) /* leaf refs carry the byte offset / 16 of an 80-B pair record in bits 4-30 (jade_trace.h; jade_scene_create checks the pair count) */
 #define JADE_MAX_LEAF 15
 #define JADE_SKIP_CAMERA (-2) /* PathState.skip: camera ray (no source triangle, origin = PathState.eye) */
 #define JADE_INF_F 2147483647.0f /* #define INF, PathTrace.cu:23 */
@@ -42,22 +42,21 @@
 #ifndef JADE_LDS_FIFO
 #define JADE_LDS_FIFO 4
 #endif
-/* leaf cursors waiting for their triangle tests, same LDS column (power of two) */
-#define JADE_LDS_STATE 9  /* ray-state words, same column (jade_trace.h): 21 words per lane */
-// k_trace and k_light run 256-thread workgroups, 5 / 4 per CU; each block stages the top of the BVH in LDS once per
-// launch (JADE_LDS_TOP_NODES node records, the ones with the largest boxes: jade_scene_create orders the internal nodes
-// by box area so that any prefix is a connected top).  A visit of such a node is four ds_read_b128 of a plane layout
-// instead of four 16-B gathers through the vector-memory path.  Measured: -3 % of k_trace.  What did NOT
-// pay: one 1024-thread workgroup per CU with 1 272 nodes staged (4 waves/SIMD: +11 % time from the lost occupancy,
-// -3 % from the staging) - the kernel is bound by VALU issue, not by that path (an extra 16-B gather per visit costs
-// +0.5 %), so LDS staging buys little and occupancy matters more.
+/* k_light: leaf cursors waiting for their triangle tests, same LDS column (power of two) */
+#define JADE_LDS_STATE 9  /* k_light: ray-state words, same column (jade_trace.h): 21 words per lane */
+// k_trace and k_light run 256-thread workgroups, 4 per CU; each block stages the top of the BVH in LDS once per launch
+// (the node records with the largest boxes: jade_scene_create orders the internal nodes by box area so that any prefix
+// is a connected top).  A visit of such a node is four ds_read_b128 of a plane layout instead of four 16-B gathers
+// through the vector-memory path: 40 % of k_trace's node visits on C3 with 160 nodes.  Measured: a
+// few per cent, with the FIFO form of k_trace (bound by VALU issue) as with the final one (bound by latency); one
+// 1024-thread workgroup per CU with 768-1 272 nodes staged did not pay either time.
 #ifndef JADE_TRACE_BLOCK
 #define JADE_TRACE_BLOCK 256
 #endif
 #ifndef JADE_TRACE_TOP_NODES
 #define JADE_TRACE_TOP_NODES 160 /* k_trace's share of the top (<= JADE_LDS_TOP_NODES): 16 KB of columns + 8 KB of rings + 10 KB of nodes = 34 KB, 4 blocks per CU.  96 nodes (30 KB, 5 blocks): the same speed on C3, 5 % slower on C5; 224: no better */
 #endif
-#ifndef JADE_LDS_TOP_NODES  /* 0 = no staging (A/B builds); 5 blocks x (21 KB of columns + 10 KB of nodes) = 155 of the CU's 160 KB */
+#ifndef JADE_LDS_TOP_NODES  /* 0 = no staging (A/B builds); k_light: 21 KB of columns + 10 KB of nodes per block */
 #define JADE_LDS_TOP_NODES 160 /* k_light's; k_trace per 1024-spp step of C3 (round 2, FIFO form): 570 ms without, 552 with 80, 545 with 160 */
 #endif
 #define JADE_RECORD_MEMORY 0.60 /* share of the free device memory that path records + partial sums may take: paths in \

@@ -9,25 +9,21 @@
 // ternary min/max of hitAABB (:484-494, :764-765).
 //
 // What is different is how the work is laid out for a 64-lane wavefront:
-//   - one ray per lane, rays taken from a compacted queue by persistent
-//     workgroups: a wave claims a chunk with one atomic and refills its idle
-//     lanes from that chunk, so short rays do not leave lanes idle behind long ones;
-//   - a lane walks nodes without stopping at leaves (a leaf it meets goes into a small
-//     FIFO) and tests triangles from the head of that FIFO; a wave iteration runs ONE
-//     kind of work for all lanes that have some (see RayState);
-//   - the near child is followed directly and only the far child is pushed,
-//     which visits nodes in exactly the reference's order with half the stack
-//     traffic;
-//   - a lane's column of LDS words, word[k][lane] (bank-conflict free: lane l always
-//     hits bank l % 32 of its half-wave), holds the stack (8 levels cover 99.6 % of
-//     the rays of the benchmark scenes, deeper levels spill to a per-lane global
-//     area, JADE_BVH_STACK_CAPACITY entries in total), the leaf FIFO, and the parts of
-//     the ray state that the triangle test does not read (1/dir, the best hit);
-//   - both children's boxes come from the parent's 64-B record, interleaved so that
-//     the two slab tests — and the p1/p2 half of the triangle test — run as packed
-//     fp32 (v_pk_*_f32): the kernel is VALU-bound (see jade_device.h);
-//   - 1/dir and normalize(dir), which the reference recomputes per node and
-//     per triangle (:710, :759), are computed once per ray — same values.
+//   - a lane walks one ray, rays taken from a compacted queue by persistent workgroups (k_trace: a wave claims a chunk
+//     with one atomic and refills its idle lanes from it, so short rays do not leave lanes idle behind long ones) or
+//     from the lane's own path (k_light);
+//   - the walk never stops at a leaf: the leaves a ray meets are queued and their triangles tested as a second stream of
+//     work - by the same lane from a small FIFO (k_light: RayState), or by ANY lane of the wave from a ring in LDS, with
+//     hit candidates resolved 64 at a time (k_trace: WalkState / WaveTrace at the end of this file);
+//   - the near child is followed directly and only the far child is pushed, which visits nodes in exactly the
+//     reference's order with half the stack traffic;
+//   - a lane's column of LDS words, word[k][lane] (bank-conflict free), holds the stack (8 levels cover 99.6 % of the
+//     rays of the benchmark scenes, deeper levels spill to a per-lane global area, JADE_BVH_STACK_CAPACITY entries in
+//     total) and the parts of the ray state that the triangle test does not read (1/dir, the best hit);
+//   - both children's boxes come from the parent's 64-B record, interleaved so that the two slab tests run as packed
+//     fp32 (v_pk_*_f32), and triangles are tested two at a time from 80-B pair records, packed across the two;
+//   - 1/dir and normalize(dir), which the reference recomputes per node and per triangle (:710, :759), are computed
+//     once per ray - same values.
 #pragma once
 #include "jade_device.h"
 
@@ -39,9 +35,6 @@ struct TraceHit {
 
 // Development ablations (cdna_hip_programming.md rule 17): JADE_ABLATE_* repeat a
 // piece of work without changing any result, to price that piece.  Off in product builds.
-#ifndef JADE_ABLATE_TRI
-#define JADE_ABLATE_TRI 0
-#endif
 #ifndef JADE_ABLATE_SLAB
 #define JADE_ABLATE_SLAB 0
 #endif
