@@ -541,6 +541,7 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
   r.cur = JADE_REF_NONE;
   r.sp = stk.col;
   r.pushed = 0;
+  r.inv = jv(0, 0, 0);
   WaveTrace wt;  // the wave's rings of leaves to test and of hit candidates, and the item this lane is testing (jade_trace.h)
   wt.init(lds_addr_of(&lds_wq[threadIdx.x >> 6][0]), lds_addr_of(&lds_hq[threadIdx.x >> 6][0]), lane);
   for (;;) {

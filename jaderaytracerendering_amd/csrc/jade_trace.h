@@ -239,7 +239,7 @@ static __device__ __forceinline__ jvec3 ray_hit_point(const LdsStack& stk) {
 // the leaf met (0 = none); cur and sp advance.
 template <bool GENERAL, int W_INV, int W_DUMMY, int TOPN>
 static __device__ __forceinline__ uint32_t node_core(uint32_t& cur_io, uint32_t& sp_io, const RayOD& od, const DevScene& S, const LdsStack& stk, bool room,
-                                                     uint32_t& vcnt) {
+                                                     uint32_t& vcnt, const jvec3* inv_reg = nullptr) {
   const uint32_t cur = cur_io;
   const bool is_leaf = (int32_t)cur < 0;
   const uint32_t node = is_leaf ? 0u : cur;  // such a lane reads record 0 and ignores it
@@ -289,7 +289,8 @@ static __device__ __forceinline__ uint32_t node_core(uint32_t& cur_io, uint32_t&
     rf = *reinterpret_cast<const uint2*>(nd + 3);
   }
 #endif
-  const jvec3 inv = jv(lds_getf(stk, W_INV), lds_getf(stk, W_INV + 1), lds_getf(stk, W_INV + 2));
+  // 1/d: from the caller's registers (k_trace, which has them to spare at 4 waves per SIMD) or from the lane's column
+  const jvec3 inv = inv_reg ? *inv_reg : jv(lds_getf(stk, W_INV), lds_getf(stk, W_INV + 1), lds_getf(stk, W_INV + 2));
   float d1, d2;
 #if JADE_ABLATE_SLAB
   {
@@ -506,9 +507,10 @@ static __device__ __forceinline__ void ray_step_tri_s(RayState& r, const DevScen
 //   * a ray has ended when its walk has and as many of its leaves have been finished (an LDS counter in its column,
 //     ds_add by whoever finishes one) as it pushed.  Its hit point is computed then, once, from the winning triangle
 //     (the same statements as in the test: same bits), instead of travelling with every candidate.
-// A lane's column: the stack, 1/d, the best hit {distance, sequence, record | A/B}, the finished-leaf counter, a dummy.
+// A lane's column: the stack, the best hit {distance, sequence, record | A/B}, the finished-leaf counter, a dummy (1/d is
+// in registers: the kernel runs 4 waves per SIMD and has them to spare).
 // ---------------------------------------------------------------------------------------------------------------
-enum { TW_INVX = JADE_LDS_STACK, TW_INVY, TW_INVZ, TW_BEST_DIST, TW_BEST_SEQ, TW_BEST_REF, TW_FINISHED, TW_DUMMY, TW_END };
+enum { TW_BEST_DIST = JADE_LDS_STACK, TW_BEST_SEQ, TW_BEST_REF, TW_FINISHED, TW_DUMMY, TW_END };
 #ifndef JADE_WQ
 #define JADE_WQ 128 /* items a wave's ring holds (a power of two, >= 128: a walk unit may push 64) */
 #endif
@@ -527,6 +529,7 @@ struct WalkState {
   uint32_t cur;     // internal-node ref, a leaf ref (a far child off the stack), or JADE_REF_NONE = walk finished
   uint32_t sp;      // LDS byte address of the next free stack level
   uint32_t pushed;  // leaves met so far = the next leaf's sequence number
+  jvec3 inv;        // 1/d
 };
 static __device__ __forceinline__ void lds_st_v(uint32_t addr, uint32_t v) { *(volatile jade_lds_u32*)(__SIZE_TYPE__)addr = v; }
 static __device__ __forceinline__ uint32_t lds_ld_v(uint32_t addr) { return *(volatile jade_lds_u32*)(__SIZE_TYPE__)addr; }
@@ -542,9 +545,7 @@ static __device__ __forceinline__ void walk_begin(WalkState& r, const LdsStack& 
   r.sp = stk.col;
   r.pushed = 0;
   r.cur = S.root_ref;
-  lds_putf(stk, TW_INVX, inv.x);
-  lds_putf(stk, TW_INVY, inv.y);
-  lds_putf(stk, TW_INVZ, inv.z);
+  r.inv = inv;
   lds_putf(stk, TW_BEST_DIST, JADE_INF_F);
   lds_put(stk, TW_BEST_SEQ, 0xffffffffu);
   lds_put(stk, TW_BEST_REF, 0xffffffffu);
@@ -553,7 +554,7 @@ static __device__ __forceinline__ void walk_begin(WalkState& r, const LdsStack& 
 // One unit of the walk for a lane whose walk has not ended.  Returns the leaf met (0 = none): the caller queues it.
 template <bool GENERAL>
 static __device__ __forceinline__ uint32_t walk_step(WalkState& r, const DevScene& S, const LdsStack& stk, uint32_t& vcnt) {
-  const uint32_t leafv = node_core<GENERAL, TW_INVX, TW_DUMMY, JADE_TRACE_TOP_NODES>(r.cur, r.sp, r.od, S, stk, true, vcnt);
+  const uint32_t leafv = node_core<GENERAL, 0, TW_DUMMY, JADE_TRACE_TOP_NODES>(r.cur, r.sp, r.od, S, stk, true, vcnt, &r.inv);
   return (leafv & 15u) != 0 ? leafv : 0u;  // (an empty leaf cannot happen for a valid BVH)
 }
 
