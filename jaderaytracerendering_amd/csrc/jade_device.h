@@ -54,7 +54,7 @@
 #define JADE_TRACE_BLOCK 256
 #endif
 #ifndef JADE_TRACE_TOP_NODES
-#define JADE_TRACE_TOP_NODES 160 /* k_trace's share of the top (<= JADE_LDS_TOP_NODES): 16 KB of columns + 8 KB of rings + 10 KB of nodes = 34 KB, 4 blocks per CU.  96 nodes (30 KB, 5 blocks): the same speed on C3, 5 % slower on C5; 224: no better */
+#define JADE_TRACE_TOP_NODES 160 /* k_trace's share of the top (<= JADE_LDS_TOP_NODES): 13 KB of columns + 8 KB of rings + 10 KB of nodes = 31 KB per block; 4 blocks per CU (102 VGPRs).  96 nodes (30 KB, 5 blocks): the same speed on C3, 5 % slower on C5; 224: no better */
 #endif
 #ifndef JADE_LDS_TOP_NODES  /* 0 = no staging (A/B builds); k_light: 21 KB of columns + 10 KB of nodes per block */
 #define JADE_LDS_TOP_NODES 160 /* k_light's; k_trace per 1024-spp step of C3 (round 2, FIFO form): 570 ms without, 552 with 80, 545 with 160 */
