@@ -169,6 +169,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         scene.step(spp_step, st)  # synchronous; a step may hand its last few paths to the next one (jade_rt.h)
+    syncs_in_steps = int(st.host_syncs)
     scene.flush(st)  # ... and the timed steps' own inside it: every sample of the K steps is done before the clock stops
     barrier()
     dt = time.perf_counter() - t0
@@ -276,7 +277,10 @@ def main():
             "rays_by_call_site": {k[5:]: float(vals[6 + i].item()) for i, k in enumerate(cls_keys)},
             "gather_ms": gather_ms,
             "frame_ok": frame_ok,
-            "host_syncs_per_step": st.host_syncs / max(args.steps, 1),
+            # host waits for the device: per step (the fused first pass, then ONE batch of up to 32 shade / trace passes that
+            # stops itself at the carry-over point), and in the flush that finishes the last paths of the render
+            "host_syncs_per_step": syncs_in_steps / max(args.steps, 1),
+            "host_syncs_in_final_flush": int(st.host_syncs) - syncs_in_steps,
             "scene_build_s": build_s,
             "bvh": args.bvh, "device_bvh_ms": dev_build_ms,
             "nodes_per_ray": float(vals[1].item()) / rays_all, "tris_per_ray": float(vals[2].item()) / rays_all,

@@ -444,8 +444,17 @@ static __device__ __forceinline__ void shade_tail(const PathState& P, int p, uin
 // the records that kernel handed over, whose count lives on the device: n_dev).  75 VGPRs, 6 waves/SIMD (JADE_SHADE_WAVES).
 __global__ __launch_bounds__(JADE_SHADE_BLOCK, JADE_SHADE_WAVES) void k_shade(DevScene S, PathState P, RenderConst R, const int32_t* tile_ids,
                                                uint32_t target_spp, const uint32_t* list, uint32_t n_host, const uint32_t* n_dev,
-                                               uint32_t* active_out, uint32_t* queue, QueueCtl* qc, DevCounters* ctr) {
+                                               uint32_t* active_out, uint32_t* queue, QueueCtl* qc, DevCounters* ctr, const QueueCtl* prev,
+                                               uint32_t stop_below) {
   const uint32_t n = n_dev ? *n_dev : n_host;
+  // A pass of a batch (prev = the pass before it, on the device): nothing to do once the paths have ended (that pass
+  // emitted no ray) or once fewer than stop_below records are active - the point where the host would hand the rest to
+  // the next step (carry-over).  Such a pass leaves the lists alone and passes the count on, so that every later pass
+  // of the batch stops too and the host finds, in the ring, where the batch really ended.
+  if (prev && (prev->count == 0 || n < stop_below)) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) qc->active = prev->count == 0 ? 0u : n;
+    return;
+  }
   if (blockIdx.x * blockDim.x >= n) return;  // block-uniform: the grid is sized for an upper bound of n_dev
   const uint32_t t_idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int p = t_idx < n ? (int)list[t_idx] : P.npix;
@@ -475,7 +484,7 @@ __global__ __launch_bounds__(JADE_LEAN_BLOCK) void k_shade_lean(DevScene S, Path
   shade_tail<true, JADE_LEAN_BLOCK / 64>(P, p, st, c, defer, nullptr, heavy_out, queue, qc, ctr);
 }
 
-#define JADE_CTL_RING 16 /* QueueCtl records: entry 0 for passes the host follows one by one, all of them for a batch of passes */
+#define JADE_CTL_RING 32 /* QueueCtl records: entry 0 for passes the host follows one by one, all of them for a batch of passes */
 #ifndef JADE_TRACE_NT
 #define JADE_TRACE_NT 1 /* k_trace reads and writes the ray records with non-temporal hints */
 #endif
@@ -512,6 +521,7 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
   stk.stride_spill = gridDim.x * blockDim.x;
   stk.top = nullptr;
   stk.top_k = 0;
+  if (qc->count == 0) return;  // (a pass of a batch behind the one that ended the step: nothing was queued)
   __shared__ float4 lds_top[4 * JADE_TRACE_TOP_NODES];
   {  // stage the top of the tree: record i's j-th 16 bytes -> plane j, entry i (coalesced reads of S.nodes)
     const uint32_t k = S.top_k < JADE_TRACE_TOP_NODES ? S.top_k : JADE_TRACE_TOP_NODES;
@@ -1512,7 +1522,7 @@ static hipError_t sum_counters(jade_scene* s, DevCounters* out) {
 
 // shade/trace passes until a shade pass emits no ray (or the step may carry the rest over).  The host follows the first
 // passes of a step one by one (it picks the schedule from the counts) and the list-mode passes in batches of 8-16.
-static int run_passes(jade_scene* s, uint32_t target_spp, bool may_carry, double* ms_out, double* trace_ms_out, uint64_t* launches_out) {
+static int run_passes(jade_scene* s, int64_t from_spp, uint32_t target_spp, bool may_carry, double* ms_out, double* trace_ms_out, uint64_t* launches_out) {
   const int npix = s->ps.npix;
   QueueCtl* qc = s->b_ctl.as<QueueCtl>();
   for (hipEvent_t& e : s->ev)
@@ -1523,24 +1533,30 @@ static int run_passes(jade_scene* s, uint32_t target_spp, bool may_carry, double
   double trace_ms = 0;
   uint64_t launches = 0;
   s->tail_pending = false;  // whatever an earlier step left is part of this call's work
-  // the records with work in this step
-  uint32_t host_ctl[3] = {0, 0, 0};
-  HIP_TRY(hipMemsetAsync(qc, 0, 12, s->stream));
-  hipLaunchKernelGGL(k_arm, dim3((unsigned)(((size_t)npix + JADE_ARM_BLOCK * JADE_ARM_PER_THREAD - 1) / (JADE_ARM_BLOCK * JADE_ARM_PER_THREAD))), dim3(JADE_ARM_BLOCK), 0, s->stream, s->ps, target_spp,
-                     s->b_active[0].as<uint32_t>(), qc);
-  HIP_TRY(hipMemcpyAsync(host_ctl, qc, 12, hipMemcpyDeviceToHost, s->stream));
-  HIP_TRY(hipStreamSynchronize(s->stream));
-  s->host_syncs += 1;
-  uint32_t n_active = host_ctl[1];
-  const uint32_t n_armed = n_active;  // records with work at the start of this call
-  int cur = 0, pass_no = 0;
-  const bool log_passes = getenv("JADE_LOG_PASSES") != nullptr;
   // While at least a quarter of the records are active, a pass is k_shade_lean over all records
   // (record order, no list) followed by k_shade over what it handed over; below that, k_shade alone
   // over the active list, which k_arm rebuilds once at the switch.  JADE_SHADE_SPLIT=0: always the list.
   const bool split_ok = !(getenv("JADE_SHADE_SPLIT") && atoi(getenv("JADE_SHADE_SPLIT")) == 0);
   // JADE_FUSED=0: the first pass as shade / trace passes too (k_shade_lean), the schedule before k_light existed
   const bool fused = split_ok && !(getenv("JADE_FUSED") && atoi(getenv("JADE_FUSED")) == 0);
+  // the records with work in this step: all of them when the step gives every record a sample (k_light then walks the
+  // records itself); otherwise - a flush, a step of fewer samples than records per pixel - k_arm lists and counts them
+  uint32_t host_ctl[3] = {0, 0, 0};
+  uint32_t n_active;
+  if (fused && s->ps.stride == 0 && (int64_t)target_spp - from_spp >= (int64_t)s->ps.rpp) {
+    n_active = (uint32_t)npix;
+  } else {
+    HIP_TRY(hipMemsetAsync(qc, 0, 12, s->stream));
+    hipLaunchKernelGGL(k_arm, dim3((unsigned)(((size_t)npix + JADE_ARM_BLOCK * JADE_ARM_PER_THREAD - 1) / (JADE_ARM_BLOCK * JADE_ARM_PER_THREAD))), dim3(JADE_ARM_BLOCK), 0, s->stream, s->ps, target_spp,
+                       s->b_active[0].as<uint32_t>(), qc);
+    HIP_TRY(hipMemcpyAsync(host_ctl, qc, 12, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    s->host_syncs += 1;
+    n_active = host_ctl[1];
+  }
+  const uint32_t n_armed = n_active;  // records with work at the start of this call
+  int cur = 0, pass_no = 0;
+  const bool log_passes = getenv("JADE_LOG_PASSES") != nullptr;
   bool have_list = true;  // b_active[cur] lists the active records
   bool light_timed = false;
   float shade_ms = 0, lean_ms = 0;
@@ -1551,21 +1567,31 @@ static int run_passes(jade_scene* s, uint32_t target_spp, bool may_carry, double
   };
   // JADE_BATCH=0: the host follows every pass (the schedule before batching existed)
   const bool batching = !(getenv("JADE_BATCH") && atoi(getenv("JADE_BATCH")) == 0);
+  bool closed_by_batch = false;  // the wait at the end of a batch was also the wait for the end of the step
   while (n_active) {
     const bool lean_mode = split_ok && (uint64_t)n_active * 4 >= (uint64_t)npix;
     if (!lean_mode && have_list && batching && !log_passes && pass_no > 0) {
       // ---- a BATCH of list-mode passes without the host in between: pass j's k_shade takes its length from the record
       // count pass j-1 left on the device (QueueCtl ring), k_trace sizes its chunks itself; a pass that finds nothing
       // to do is three empty launches.  The host looks once per batch: where the paths ended, whether to carry.
-      const int B = n_active > (1u << 20) ? 8 : JADE_CTL_RING;  // (long passes: a shorter batch, so that the carry point is not overshot by much)
+      const int B = JADE_CTL_RING;
       const unsigned nbb = (n_active + JADE_SHADE_BLOCK - 1) / JADE_SHADE_BLOCK;  // the active count only shrinks: an upper bound for all
+      // the carry-over point, for the device: passes of the batch behind it do nothing (k_shade)
+      uint32_t stop_below = 0;
+      if (may_carry) {
+        const uint64_t a = std::min<uint64_t>(JADE_CARRY_RECORDS, ((uint64_t)n_armed + 1023) / 1024);  // act < CARRY_RECORDS && act * 1024 < n_armed
+        const uint64_t b = carry_frac > 0 ? (uint64_t)std::ceil(carry_frac * (double)n_armed) : 0;     // act < carry_frac * n_armed
+        stop_below = (uint32_t)std::min<uint64_t>(std::max(a, b), 0xffffffffu);
+      }
       for (hipEvent_t& e : s->ev_batch)
         if (!e) HIP_TRY(hipEventCreate(&e));
       HIP_TRY(hipMemsetAsync(qc, 0, sizeof(QueueCtl) * B, s->stream));
+      const int cur0 = cur;
       for (int j = 0; j < B; ++j) {
         hipLaunchKernelGGL(k_shade, dim3(nbb), dim3(JADE_SHADE_BLOCK), 0, s->stream, s->dev, s->ps, s->rc, s->b_tiles.as<int32_t>(),
                            target_spp, s->b_active[cur].as<uint32_t>(), n_active, j ? &qc[j - 1].active : (const uint32_t*)nullptr,
-                           s->b_active[cur ^ 1].as<uint32_t>(), s->b_queue.as<uint32_t>(), qc + j, s->b_ctr.as<DevCounters>());
+                           s->b_active[cur ^ 1].as<uint32_t>(), s->b_queue.as<uint32_t>(), qc + j, s->b_ctr.as<DevCounters>(),
+                           j ? qc + (j - 1) : (const QueueCtl*)nullptr, stop_below);
         cur ^= 1;
         HIP_TRY(hipEventRecord(s->ev_batch[2 * j], s->stream));
         hipLaunchKernelGGL(k_trace, dim3((unsigned)s->trace_blocks), dim3(JADE_TRACE_BLOCK), 0, s->stream, s->dev, s->ps,
@@ -1575,6 +1601,7 @@ static int run_passes(jade_scene* s, uint32_t target_spp, bool may_carry, double
       HIP_TRY(hipGetLastError());
       QueueCtl host_ring[JADE_CTL_RING];
       HIP_TRY(hipMemcpyAsync(host_ring, qc, sizeof(QueueCtl) * B, hipMemcpyDeviceToHost, s->stream));
+      HIP_TRY(hipEventRecord(ev1, s->stream));  // the end of the step, if this batch is its last (recorded again otherwise)
       HIP_TRY(hipStreamSynchronize(s->stream));
       s->host_syncs += 1;
       if (trace_pending) {  // the k_trace launch of the pass before the batch
@@ -1584,11 +1611,19 @@ static int run_passes(jade_scene* s, uint32_t target_spp, bool may_carry, double
         launches += 1;
         trace_pending = false;
       }
-      bool ended = false;
+      bool ended = false, stopped = false;
+      int real = 0;  // passes of the batch that ran (the rest found the paths ended, or the carry-over point reached)
       for (int j = 0; j < B; ++j) {
-        if (host_ring[j].count == 0) {  // this pass emitted nothing: every path has ended (later passes of the batch were empty)
-          n_active = 0;
-          ended = true;
+        if (host_ring[j].count == 0) {
+          if (host_ring[j].active == 0) {  // this pass emitted nothing and left nothing active: every path has ended
+            // (a pass that ran and finished the last paths, or - behind it - one that found nothing to do)
+            if (j == 0 || host_ring[j - 1].count != 0) real = j + 1;
+            n_active = 0;
+            ended = true;
+          } else {  // the device stopped here: fewer than stop_below records are active
+            n_active = host_ring[j].active;
+            stopped = true;
+          }
           break;
         }
         float t = 0;
@@ -1597,10 +1632,16 @@ static int run_passes(jade_scene* s, uint32_t target_spp, bool may_carry, double
         launches += 1;
         n_active = host_ring[j].active;
         ++pass_no;
+        real = j + 1;
       }
-      if (ended) break;
-      if (carry_now(n_active)) {
+      cur = cur0 ^ (real & 1);  // the list the last pass that ran wrote
+      if (ended) {
+        closed_by_batch = true;
+        break;
+      }
+      if (stopped || carry_now(n_active)) {
         s->tail_pending = true;
+        closed_by_batch = true;
         break;
       }
       continue;
@@ -1637,10 +1678,13 @@ static int run_passes(jade_scene* s, uint32_t target_spp, bool may_carry, double
       }
       HIP_TRY(hipEventRecord(s->ev_light[1], s->stream));
       if (log_passes) HIP_TRY(hipEventRecord(sm, s->stream));
+      // k_light has run every other record to the end of its samples, so the records this pass leaves active ARE the active
+      // list (written over k_light's regions, which k_heavy_pack has emptied): no k_arm scan of all records after it
       hipLaunchKernelGGL(k_shade, dim3(nb), dim3(JADE_SHADE_BLOCK), 0, s->stream, s->dev, s->ps, s->rc, s->b_tiles.as<int32_t>(),
-                         target_spp, s->b_active[1].as<uint32_t>(), 0u, &qc->heavy, (uint32_t*)nullptr, s->b_queue.as<uint32_t>(), qc,
-                         s->b_ctr.as<DevCounters>());
-      have_list = false;
+                         target_spp, s->b_active[1].as<uint32_t>(), 0u, &qc->heavy, s->b_active[0].as<uint32_t>(), s->b_queue.as<uint32_t>(), qc,
+                         s->b_ctr.as<DevCounters>(), (const QueueCtl*)nullptr, 0u);
+      have_list = true;
+      cur = 0;
     } else if (lean_mode) {
       // b_active[1] carries the hand-over list; no active list is kept in this mode
       hipLaunchKernelGGL(k_shade_lean, dim3((unsigned)((npix + JADE_LEAN_BLOCK - 1) / JADE_LEAN_BLOCK)), dim3(JADE_LEAN_BLOCK), 0,
@@ -1650,13 +1694,13 @@ static int run_passes(jade_scene* s, uint32_t target_spp, bool may_carry, double
       // only a record that was active can be handed over: n_active bounds the grid, the count stays on the device
       hipLaunchKernelGGL(k_shade, dim3(nb), dim3(JADE_SHADE_BLOCK), 0, s->stream, s->dev, s->ps, s->rc, s->b_tiles.as<int32_t>(),
                          target_spp, s->b_active[1].as<uint32_t>(), 0u, &qc->heavy, (uint32_t*)nullptr, s->b_queue.as<uint32_t>(), qc,
-                         s->b_ctr.as<DevCounters>());
+                         s->b_ctr.as<DevCounters>(), (const QueueCtl*)nullptr, 0u);
       have_list = false;
     } else {
       if (log_passes) HIP_TRY(hipEventRecord(sm, s->stream));
       hipLaunchKernelGGL(k_shade, dim3(nb), dim3(JADE_SHADE_BLOCK), 0, s->stream, s->dev, s->ps, s->rc, s->b_tiles.as<int32_t>(),
                          target_spp, s->b_active[cur].as<uint32_t>(), n_active, (const uint32_t*)nullptr,
-                         s->b_active[cur ^ 1].as<uint32_t>(), s->b_queue.as<uint32_t>(), qc, s->b_ctr.as<DevCounters>());
+                         s->b_active[cur ^ 1].as<uint32_t>(), s->b_queue.as<uint32_t>(), qc, s->b_ctr.as<DevCounters>(), (const QueueCtl*)nullptr, 0u);
       cur ^= 1;
     }
     HIP_TRY(hipGetLastError());
@@ -1722,9 +1766,11 @@ static int run_passes(jade_scene* s, uint32_t target_spp, bool may_carry, double
     launches += 1;
     trace_pending = false;
   }
-  HIP_TRY(hipEventRecord(ev1, s->stream));
-  HIP_TRY(hipEventSynchronize(ev1));
-  s->host_syncs += 1;
+  if (!closed_by_batch) {
+    HIP_TRY(hipEventRecord(ev1, s->stream));
+    HIP_TRY(hipEventSynchronize(ev1));
+    s->host_syncs += 1;
+  }
   float ms = 0;
   HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
   *ms_out = ms;
@@ -1745,7 +1791,7 @@ static int advance(jade_scene* s, int64_t from0, bool may_carry, jade_stats* st)
     if (to > s->spp_done || s->ps.stride == 0) to = s->spp_done;  // no rotation: no block barrier needed
     double m1 = 0, t1 = 0;
     uint64_t l1 = 0;
-    int rc = run_passes(s, (uint32_t)to, may_carry && s->ps.stride == 0, &m1, &t1, &l1);
+    int rc = run_passes(s, from, (uint32_t)to, may_carry && s->ps.stride == 0, &m1, &t1, &l1);
     if (rc) return rc;
     ms += m1; trace_ms += t1; launches += l1;
     from = to;
