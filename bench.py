@@ -214,7 +214,8 @@ def main():
         roof = {"bound": "valu", "kernel": "k_trace", "achieved": None, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s", "frac": None,
                 "traffic": None, "avg_launch_ms": st.trace_ms / launches, "launches": launches,
                 "trace_share_of_step_time": trace_s / (st.kernel_ms * 1e-3) if st.kernel_ms else None,
-                # what a profiler sees for the same command: every k_trace launch of the process, warm-up included
+                # what a profiler sees for the same command: every k_trace launch of the process, warm-up included (launches count
+                # the empty ones behind the end of a step's batch too - they are launches, of a few microseconds)
                 "launches_incl_warmup": launches + int(st_w.trace_launches),
                 "avg_launch_ms_incl_warmup": (st.trace_ms + st_w.trace_ms) / max(launches + int(st_w.trace_launches), 1),
                 "rays_per_launch": rays_rank / launches, "rays_traced_by_this_kernel": rays_rank,

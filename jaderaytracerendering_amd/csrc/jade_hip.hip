@@ -1612,7 +1612,8 @@ static int run_passes(jade_scene* s, int64_t from_spp, uint32_t target_spp, bool
         trace_pending = false;
       }
       bool ended = false, stopped = false;
-      int real = 0;  // passes of the batch that ran (the rest found the paths ended, or the carry-over point reached)
+      int real = 0;        // passes of the batch that ran (the rest found the paths ended, or the carry-over point reached)
+      int pass_timed = 0;  // k_trace launches of the batch accounted for so far
       for (int j = 0; j < B; ++j) {
         if (host_ring[j].count == 0) {
           if (host_ring[j].active == 0) {  // this pass emitted nothing and left nothing active: every path has ended
@@ -1630,9 +1631,18 @@ static int run_passes(jade_scene* s, int64_t from_spp, uint32_t target_spp, bool
         HIP_TRY(hipEventElapsedTime(&t, s->ev_batch[2 * j], s->ev_batch[2 * j + 1]));
         trace_ms += t;
         launches += 1;
+        pass_timed = j + 1;
         n_active = host_ring[j].active;
         ++pass_no;
         real = j + 1;
+      }
+      // the launches behind the end of the step were made all the same (k_trace leaves at its first instruction): they count
+      // as launches, with their few microseconds, so that launches and time are what a profiler sees
+      for (int j = pass_timed; j < B; ++j) {
+        float t = 0;
+        HIP_TRY(hipEventElapsedTime(&t, s->ev_batch[2 * j], s->ev_batch[2 * j + 1]));
+        trace_ms += t;
+        launches += 1;
       }
       cur = cur0 ^ (real & 1);  // the list the last pass that ran wrote
       if (ended) {
