@@ -106,9 +106,9 @@ struct PathState {
   int32_t rpp;          // records per pixel
   int32_t stride;       // pixel rotation per sample (see above)
   int32_t nslots;
-  uint32_t* rng;        // Wang-hash state of the sample in flight
-  uint32_t* done;       // samples this record has finished
-  uint32_t* stage;      // stage | depth << 8 | flags << 16
+  uint4* hdr;           // [npix] what every pass of every record reads, one 16-B word: {rng: Wang-hash state of the sample in
+                        // flight, done: samples this record has finished, stage | depth << 8 | flags << 16, 0}.  Read in record
+                        // order by k_light (coalesced); for k_shade, whose records are scattered, one sector instead of three
   float* sum;           // [3][JADE_SAMPLE_LANES * npx] partial radiance sums per (lane, pixel)
   // The context of a path in flight, five float4 per record (only k_shade and a record k_light parks touch it; what every
   // pass of every record reads - rng, done, stage - stays in planes):

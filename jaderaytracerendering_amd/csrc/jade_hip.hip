@@ -103,8 +103,7 @@ __global__ void k_selftest(QueueCtl* q, float one) { q->fp_bad = (uint32_t)jade_
 __global__ void k_init(PathState P) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P.npix) return;
-  P.done[p] = 0;
-  P.stage[p] = ST_IDLE;
+  P.hdr[p] = make_uint4(0u, 0u, ST_IDLE, 0u);
 }
 
 #define JADE_ARM_BLOCK 1024
@@ -124,8 +123,9 @@ __global__ __launch_bounds__(JADE_ARM_BLOCK) void k_arm(PathState P, uint32_t ta
     const size_t p = base + (size_t)j * JADE_ARM_BLOCK + threadIdx.x;
     bool want = false;
     if (p < (size_t)P.npix) {
-      const uint32_t st = P.stage[p] & 255u;
-      want = st != ST_IDLE || next_sample(P, (int)p, P.done[p]).sidx < target_spp;
+      const uint4 h = P.hdr[p];
+      const uint32_t st = h.z & 255u;
+      want = st != ST_IDLE || next_sample(P, (int)p, h.y).sidx < target_spp;
     }
     const unsigned long long m = __ballot(want);
     off[j] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
@@ -185,9 +185,10 @@ static __device__ __forceinline__ void shade_record(const DevScene& S, const Pat
   // round trip deep instead of one per field (the kernel is latency-bound: PMC shows its
   // waves parked on s_waitcnt 74 % of the time).
   const int pp = p < npix ? p : 0;
-  const uint32_t word = P.stage[pp];
-  const uint32_t rng0 = P.rng[pp];
-  const uint32_t done0 = P.done[pp];
+  const uint4 hdr0 = P.hdr[pp];
+  const uint32_t word = hdr0.z;
+  const uint32_t rng0 = hdr0.x;
+  const uint32_t done0 = hdr0.y;
   const float4 slot0 = P.slot[(size_t)pp * P.nslots * 2];  // slot 0: {direction, hit}
   const int hit0 = __float_as_int(slot0.w);
   const jvec3 dir0 = jv(slot0.x, slot0.y, slot0.z);
@@ -336,9 +337,7 @@ static __device__ __forceinline__ void shade_record(const DevScene& S, const Pat
         c.c_cls += st == ST_MIRROR ? (1u << 16) : (1u << 24);
       }
     }
-    P.rng[p] = c.rng;
-    P.done[p] = done;
-    P.stage[p] = st | (c.depth << 8) | (c.flags << 16);
+    P.hdr[p] = make_uint4(c.rng, done, st | (c.depth << 8) | (c.flags << 16), 0u);
     if ((st >= ST_DIFFUSE && st <= ST_REFRACT_EXIT) || st == ST_VERTEX) {
       // (aux and auxi - words 17-19 and 7 - are begin_bounce's and consume's: written through Px while this record was shaded)
       float4* cx = P.ctx + (size_t)p * 5;
@@ -680,19 +679,20 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_LIGHT_WAVES) void k_light(De
     const size_t p64 = base + (size_t)lane;
     const bool have = p64 < (size_t)npix;
     const int p = have ? (int)p64 : 0;
-    const uint32_t word = P.stage[p];
+    const uint4 hdr0 = P.hdr[p];
+    const uint32_t word = hdr0.z;
     uint32_t st = have ? (word & 255u) : (uint32_t)ST_INVALID;
     const uint32_t rec_m = (uint32_t)p / (uint32_t)P.npx;
     const int home_pix = (int)((uint32_t)p - rec_m * (uint32_t)P.npx);
     const int tid0 = tile_ids[home_pix >> 8];
-    uint32_t done = P.done[p];
+    uint32_t done = hdr0.y;
     bool defer = false;  // hand the record to k_shade
     // a record that is in the middle of a path (carried over from the last step, its rays traced and their results
     // waiting in memory) goes to k_shade untouched, as k_shade_lean does; an idle one is this kernel's to run
     bool mine = st == ST_IDLE;
     const bool untouched = have && st != ST_IDLE && st != ST_INVALID;
     if (untouched) defer = true;
-    c.rng = P.rng[p];
+    c.rng = hdr0.x;
     c.depth = 0;
     c.flags = 0;
     c.thr = jv(1, 1, 1);
@@ -844,10 +844,8 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_LIGHT_WAVES) void k_light(De
     }
     // ---- store what the next kernel needs
     if (have && st != ST_INVALID && !untouched) {  // (a carried-over record was not touched)
-      P.rng[p] = c.rng;
-      P.done[p] = done;
+      P.hdr[p] = make_uint4(c.rng, done, st == ST_VERTEX ? ST_VERTEX | (c.depth << 8) | (c.flags << 16) : (uint32_t)ST_IDLE, 0u);
       if (st == ST_VERTEX) {  // parked: the path context, as shade_record stores it for this stage
-        P.stage[p] = ST_VERTEX | (c.depth << 8) | (c.flags << 16);
         float4* cx = P.ctx + (size_t)p * 5;
         float* cf = reinterpret_cast<float*>(cx);
         cf[0] = c.thr.x; cf[1] = c.thr.y; cf[2] = c.thr.z; cf[3] = __int_as_float(c.obj);
@@ -855,8 +853,6 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_LIGHT_WAVES) void k_light(De
         cx[2] = make_float4(c.le.x, c.le.y, c.le.z, c.src.x);
         cx[3] = make_float4(c.src.y, c.src.z, c.out.x, c.out.y);
         cf[16] = c.out.z;
-      } else {
-        P.stage[p] = ST_IDLE;
       }
     }
     // ---- hand-over: append to this wave's region
@@ -1393,7 +1389,7 @@ static int setup_state(jade_scene* s, int npx, int rpp, int nslots) {
   size_t words = 0;
   auto take = [&](size_t n) { size_t o = words; words += (n + 63) & ~(size_t)63; return o; };
   const size_t N = (size_t)npix, K = (size_t)nslots;
-  size_t o_rng = take(N), o_done = take(N), o_stage = take(N), o_sum = take(3 * (size_t)JADE_SAMPLE_LANES * npx), o_ctx = take(20 * N), o_orgs = take(4 * N), o_slot = take(8 * K * N);
+  size_t o_hdr = take(4 * N), o_sum = take(3 * (size_t)JADE_SAMPLE_LANES * npx), o_ctx = take(20 * N), o_orgs = take(4 * N), o_slot = take(8 * K * N);
   HIP_TRY(s->b_state.alloc(words * 4));
   HIP_TRY(hipMemsetAsync(s->b_state.p, 0, words * 4, s->stream));
   uint32_t* b = s->b_state.as<uint32_t>();
@@ -1410,7 +1406,7 @@ static int setup_state(jade_scene* s, int npx, int rpp, int nslots) {
     P.stride = (e && atoi(e) > 0 && per > 1) ? (npx / per) | 1 : 0;
   }
   P.nslots = nslots;
-  P.rng = b + o_rng; P.done = b + o_done; P.stage = b + o_stage;
+  P.hdr = (uint4*)(b + o_hdr);
   P.sum = (float*)(b + o_sum); P.ctx = (float4*)(b + o_ctx); P.orgs = (float4*)(b + o_orgs);
   P.slot = (float4*)(b + o_slot);
   HIP_TRY(s->b_queue.alloc(K * N * 4));
@@ -1438,7 +1434,7 @@ int jade_render_begin(jade_scene* s, const jade_render_params* rp) {
   // Records per pixel: as many paths in flight as JADE_RECORD_MEMORY of the free device memory holds (the
   // partial sums come out of the same share), whatever the image share of this GPU: more records = fewer,
   // wider passes.  288 GB is what makes 530 M paths (112 GB) for a full 1080p frame affordable.
-  const double bytes_per_record = 4.0 * (29 + 9 * nslots);  // PathState (a slot is two float4) + queue entry + two list entries
+  const double bytes_per_record = 4.0 * (30 + 9 * nslots);  // PathState (a slot is two float4) + queue entry + two list entries
   const double sums_bytes = 12.0 * JADE_SAMPLE_LANES * (double)npx64;
   size_t mem_free = 0, mem_total = 0;
   HIP_TRY(hipMemGetInfo(&mem_free, &mem_total));
