@@ -272,6 +272,11 @@ static __device__ __forceinline__ uint32_t node_core(uint32_t& cur_io, uint32_t&
         const float4 x = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(nd) + 40);
         asm volatile("" ::"v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w));
       }
+#elif JADE_ABLATE_LOAD == 3
+      {  // ... and from another 128-B LINE (two records on: records are 64 B, so `node ^ 1` shares the line that is being fetched anyway)
+        const float4 x = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.nodes) + (node ^ 2u) * 64u);
+        asm volatile("" ::"v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w));
+      }
 #elif JADE_ABLATE_LOAD == 2
       {  // ... and from ANOTHER line (the neighbouring record): +25 % look-ups and +1 line from L2 per visit
         const float4 x = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.nodes) + (node ^ 1u) * 64u);
