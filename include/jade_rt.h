@@ -34,7 +34,7 @@ extern "C" {
 
 /* bump whenever a struct layout or a documented semantic changes; callers compare
  * jade_abi_version() with the value they were compiled against */
-#define JADE_ABI_VERSION 4
+#define JADE_ABI_VERSION 5
 
 /* status codes */
 #define JADE_OK 0
@@ -252,6 +252,19 @@ int jade_owned_tile_count(int32_t width, int32_t height, int32_t tile_rank, int3
  * what bench.py and jaderaytracerendering_amd/distributed.py use.) */
 int jade_render_multi(jade_scene* const* scenes, int ndev, const jade_render_params* params,
                       float* out_rgb, uint8_t* out_bgr8, jade_stats* stats);
+
+/* What a backend holds for the render begun last (after jade_render_begin; values are the backend's own choices and
+ * never change a result - jade_render_params.max_state_bytes / .spp are what a caller steers them with):
+ *   JADE_Q_RECORDS_PER_PIXEL  HIP: samples of one pixel in flight at once (a power of two <= JADE_SAMPLE_LANES); oracle: 1
+ *   JADE_Q_STATE_BYTES        HIP: device bytes held for path records, ray queue, lists and partial sums; oracle: host
+ *                             bytes of its partial sums
+ *   JADE_Q_SUM_LANES          partial sums kept per pixel: min(JADE_SAMPLE_LANES, the announced spp rounded up to a power
+ *                             of two); grows by itself if steps add more samples than were announced
+ * (The reference has no counterpart: its one kernel keeps a pixel's whole state in registers, PathTrace.cu:1418-1474.) */
+#define JADE_Q_RECORDS_PER_PIXEL 0
+#define JADE_Q_STATE_BYTES 1
+#define JADE_Q_SUM_LANES 2
+int jade_render_query(jade_scene* scene, int what, int64_t* value);
 
 /* Single-query entry point used by the parity tests: traces `n` rays through
  * the scene's BVH with hitBVH semantics (PathTrace.cu:795-859).

@@ -6,13 +6,14 @@ reference device structs, PathTrace.cu:327-351).
 """
 import ctypes as C
 
-JADE_ABI_VERSION = 4
+JADE_ABI_VERSION = 5
 JADE_SAMPLE_LANES = 1024
 JADE_OK, JADE_ERR_INVALID, JADE_ERR_DEVICE, JADE_ERR_NOMEM, JADE_ERR_UNSUPPORTED = range(5)
 DIFFUSE, MIRROR = 0, 1
 NO_REFRACT, SUB_SURFACE, DIR_REFRACT = 0, 1, 2
 TILE_SIZE = 16
 TONEMAP_ACES, TONEMAP_REINHARD = 0, 1
+Q_RECORDS_PER_PIXEL, Q_STATE_BYTES, Q_SUM_LANES = 0, 1, 2
 
 f3 = C.c_float * 3
 f16 = C.c_float * 16
@@ -112,6 +113,7 @@ RT_SYMBOLS = {
     "jade_render_resolve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "jade_render_resolve_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "jade_render_resolve_tiles_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "jade_render_query": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]),
     "jade_owned_tile_count": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "jade_trace_rays": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.POINTER(Stats)]),

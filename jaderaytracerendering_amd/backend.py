@@ -128,6 +128,12 @@ class Scene:
             self.backend.check(self.backend.lib.jade_render_resolve_ex(self._h, int(tonemap), float(limit), pr, pb))
         return rgb, bgr
 
+    def query(self, what):
+        """jade_render_query: what the backend holds for the current render (_abi.Q_*)."""
+        v = C.c_int64(0)
+        self.backend.check(self.backend.lib.jade_render_query(self._h, int(what), C.byref(v)))
+        return v.value
+
     def resolve_tiles_device(self, dev_ptr, stream=0):
         self.backend.check(self.backend.lib.jade_render_resolve_tiles_device(self._h, C.c_void_p(dev_ptr), C.c_void_p(stream)))
 

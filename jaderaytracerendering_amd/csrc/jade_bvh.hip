@@ -242,11 +242,17 @@ __global__ __launch_bounds__(PLOC_BLOCK) void k_ploc_nn(int m, const Box6* cbox,
     const int j = i + d;
     if (d == 0 || j < 0 || j >= m) continue;
     const float a = union_area(me, tile[threadIdx.x + PLOC_RADIUS + d]);
-    // same area: the pair with the lower low end, then the lower high end
+    // Same area: a total order on PAIRS that both ends evaluate alike, so that the best pair overall is always mutual -
+    // and one that cannot chain.  With "the pair with the lowest low end" every cluster of a row of equal areas (a ribbon,
+    // instanced duplicates) chose its lower neighbour and ONE pair merged per round (600 identical triangles: 599 rounds).
+    // Nearer in Morton order first; of the two neighbours at the same distance dd, the one whose pair starts at an even
+    // multiple of dd - (2k, 2k+1), (4k, 4k+2), (4k+1, 4k+3), ...: disjoint pairs, so half of such a row merges per round.
     bool better = a < best;
     if (a == best && bj >= 0) {
-      const int lo1 = i < j ? i : j, hi1 = i < j ? j : i, lo0 = i < bj ? i : bj, hi0 = i < bj ? bj : i;
-      better = lo1 < lo0 || (lo1 == lo0 && hi1 < hi0);
+      const int d1 = d < 0 ? -d : d, d0 = bj > i ? bj - i : i - bj;
+      const int lo1 = i < j ? i : j, lo0 = i < bj ? i : bj;
+      const int odd1 = (lo1 / d1) & 1, odd0 = (lo0 / d0) & 1;
+      better = d1 < d0 || (d1 == d0 && (odd1 < odd0 || (odd1 == odd0 && lo1 < lo0)));
     }
     if (better) {
       best = a;
@@ -416,7 +422,9 @@ int build_bvh(BuildKind kind, const jade_triangle* tris, int32_t n, int32_t leaf
                        b_bhi.as<float>(), b_count.as<int>(), b_cid[0].as<int>(), b_cbox[0].as<Box6>());
     int m = n, id_base = n - 1, cur = 0;
     for (int round = 0; m > 1; ++round) {
-      if (round > 4 * 64) return jade_fail(JADE_ERR_DEVICE, "PLOC did not converge");  // every round merges at least one pair
+      // every round merges at least one pair (the best pair overall is mutual); regular geometry merges half of a row of
+      // equal areas per round (k_ploc_nn's tie rule), so a build is some tens of rounds - the bound is a guard, not a budget
+      if (round > 2048) return jade_fail(JADE_ERR_DEVICE, "PLOC did not converge in 2048 rounds");
       const unsigned bm = (unsigned)((m + PLOC_BLOCK - 1) / PLOC_BLOCK);
       hipLaunchKernelGGL(k_ploc_nn, dim3(bm), dim3(PLOC_BLOCK), 0, st, m, b_cbox[cur].as<Box6>(), b_nn.as<int>());
       hipLaunchKernelGGL(k_ploc_mark, dim3(bm), dim3(PLOC_BLOCK), 0, st, m, b_nn.as<int>(), b_f64.as<unsigned long long>());

@@ -109,7 +109,8 @@ struct PathState {
   uint4* hdr;           // [npix] what every pass of every record reads, one 16-B word: {rng: Wang-hash state of the sample in
                         // flight, done: samples this record has finished, stage | depth << 8 | flags << 16, 0}.  Read in record
                         // order by k_light (coalesced); for k_shade, whose records are scattered, one sector instead of three
-  float* sum;           // [3][JADE_SAMPLE_LANES * npx] partial radiance sums per (lane, pixel)
+  int32_t sum_lanes;    // partial sums kept per pixel: min(JADE_SAMPLE_LANES, announced spp rounded up to a power of two) >= rpp
+  float* sum;           // [3][sum_lanes * npx] partial radiance sums per (lane, pixel); sample s adds into lane s % JADE_SAMPLE_LANES
   // The context of a path in flight, five float4 per record (only k_shade and a record k_light parks touch it; what every
   // pass of every record reads - rng, done, stage - stays in planes):
   //   {thr.xyz, obj} {acc.xyz, auxi} {le.xyz, src.x} {src.y, src.z, out.x, out.y} {out.z, aux.xyz}

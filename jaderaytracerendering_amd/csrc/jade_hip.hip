@@ -29,6 +29,7 @@
 #include <thread>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -279,7 +280,7 @@ static __device__ __forceinline__ void shade_record(const DevScene& S, const Pat
         {
           const NextSample cs = next_sample_mh(P, rec_m, (uint32_t)home_pix, done);  // the sample that just ended
           const size_t si = (size_t)(cs.sidx % JADE_SAMPLE_LANES) * (size_t)P.npx + (size_t)cs.pixel;
-          const size_t sn = (size_t)JADE_SAMPLE_LANES * (size_t)P.npx;
+          const size_t sn = (size_t)P.sum_lanes * (size_t)P.npx;
           st3w(P.sum, sn, si, jv_add(ld3w(P.sum, sn, si), color));
         }
         done += 1;
@@ -663,7 +664,7 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_LIGHT_WAVES) void k_light(De
   }
 #endif
   const int npix = P.npix;
-  const size_t sn = (size_t)JADE_SAMPLE_LANES * (size_t)P.npx;
+  const size_t sn = (size_t)P.sum_lanes * (size_t)P.npx;
   uint32_t vcnt = 0, tcnt = 0, n_mirror = 0;
   ShadeCtx c;
   c.n_emit_rays = 0;
@@ -937,9 +938,12 @@ __global__ void k_resolve(PathState P, RenderConst R, const int32_t* tile_ids, f
   jvec3 m = jv(0, 0, 0);
   if (valid) {
     // add the JADE_SAMPLE_LANES partial sums in lane order (jade_rt.h)
-    const size_t sn = (size_t)JADE_SAMPLE_LANES * (size_t)P.npx;
+    const size_t sn = (size_t)P.sum_lanes * (size_t)P.npx;
     jvec3 s = ld3w(P.sum, sn, (size_t)p);
-    for (int l = 1; l < JADE_SAMPLE_LANES; ++l) s = jv_add(s, ld3w(P.sum, sn, (size_t)l * (size_t)P.npx + (size_t)p));
+    for (int l = 1; l < P.sum_lanes; ++l) s = jv_add(s, ld3w(P.sum, sn, (size_t)l * (size_t)P.npx + (size_t)p));
+    // lanes the render never needed are not kept (PathState.sum_lanes): they would all be +0.0, and adding +0.0 any number
+    // of times is adding it once (it only turns a -0.0 total into +0.0)
+    if (P.sum_lanes < JADE_SAMPLE_LANES) s = jv_add(s, jv(0.0f, 0.0f, 0.0f));
     m = jv(s.x * inv_spp, s.y * inv_spp, s.z * inv_spp);
   }
   if (out_rgb) {
@@ -1014,8 +1018,40 @@ struct DevEvent {  // an event that is destroyed on every return path
   hipError_t create() { return hipEventCreate(&e); }
 };
 
+// Development switches, read from the environment ONCE, at jade_scene_create (the product path reads no environment
+// variable per call).  Every one of them changes the schedule only, never a result (tests/test_gpu_parity.py).
+struct Tunables {
+  bool shade_split = true;    // JADE_SHADE_SPLIT=0: k_shade alone over the active list from the first pass on
+  bool fused = true;          // JADE_FUSED=0: the step's first pass as k_shade_lean + k_shade + k_trace instead of k_light
+  bool batching = true;       // JADE_BATCH=0: the host follows every pass
+  bool carry = true;          // JADE_CARRY=0: every step finishes all its paths
+  double carry_frac = JADE_CARRY_FRACTION;
+  bool log_passes = false;    // JADE_LOG_PASSES: one line per pass on stderr (forces one host wait per pass)
+  bool pixel_rotate = false;  // JADE_PIXEL_ROTATE=1
+  int records_per_pixel = 0;  // JADE_RECORDS_PER_PIXEL: test hook, results must not depend on it
+  int trace_blocks_per_cu = 0;  // JADE_TRACE_BLOCKS_PER_CU: occupancy sweeps
+  bool force_rccl = false;    // JADE_FORCE_RCCL=1 (tests): the RCCL path for a single share too
+  int sort_mode = -1;         // JADE_SORT: ray-queue ordering before k_trace (-1 = the build's default)
+  void read() {
+    auto flag0 = [](const char* n) { const char* e = getenv(n); return e && atoi(e) == 0; };
+    auto flag1 = [](const char* n) { const char* e = getenv(n); return e && atoi(e) > 0; };
+    shade_split = !flag0("JADE_SHADE_SPLIT");
+    fused = shade_split && !flag0("JADE_FUSED");
+    batching = !flag0("JADE_BATCH");
+    carry = !flag0("JADE_CARRY");
+    if (const char* e = getenv("JADE_CARRY_FRACTION")) carry_frac = atof(e);
+    log_passes = getenv("JADE_LOG_PASSES") != nullptr;
+    pixel_rotate = flag1("JADE_PIXEL_ROTATE");
+    if (const char* e = getenv("JADE_RECORDS_PER_PIXEL")) records_per_pixel = atoi(e);
+    if (const char* e = getenv("JADE_TRACE_BLOCKS_PER_CU")) trace_blocks_per_cu = atoi(e);
+    force_rccl = getenv("JADE_FORCE_RCCL") != nullptr;
+    if (const char* e = getenv("JADE_SORT")) sort_mode = atoi(e);
+  }
+};
+
 struct jade_scene {
   int device = 0;
+  Tunables tun;
   hipStream_t stream = nullptr;
   DevScene dev{};
   DevBuf b_nodes, b_tverts, b_tris, b_emit, b_mapping, b_prefix, b_segs, b_env;
@@ -1026,7 +1062,8 @@ struct jade_scene {
   jade_render_params rp{};
   RenderConst rc{};
   PathState ps{};
-  DevBuf b_state, b_tiles, b_queue, b_active[2], b_ctl, b_ctr, b_spill, b_out_rgb, b_out_bgr, b_wavecnt;
+  DevBuf b_sortkey, b_sorttmp;  // ray-queue ordering (k_sort_*): keys beside the queue, histogram / sorted queue
+  DevBuf b_state, b_sum, b_tiles, b_queue, b_active[2], b_ctl, b_ctr, b_spill, b_out_rgb, b_out_bgr, b_wavecnt;
   std::vector<int32_t> tile_ids;
   int trace_blocks = 0;
   int light_blocks = 0;       // persistent grid of k_light
@@ -1094,35 +1131,58 @@ struct Rccl {
 Rccl g_rccl;
 }  // namespace
 
+// Communicators are made once per device list and kept for the life of the process (ncclCommInitAll is a bootstrap of
+// all ranks: tens of milliseconds on 8 GPUs - not something to pay inside every frame).
+namespace {
+struct CommSet {
+  std::vector<int> devs;
+  std::vector<ncclComm_t> comms;
+};
+std::mutex g_comm_mu;
+std::vector<CommSet> g_comm_sets;
+}  // namespace
+
 // Gather of every share's resolved tile buffer (scenes[i]->b_out_rgb, npx * 3 floats) into `dst` on scenes[0]'s device,
 // share i at off[i]: one communicator per device from this one process, all sends and receives in one group.
 static int rccl_gather(jade_scene* const* scenes, int ndev, float* dst, const std::vector<size_t>& off) {
   std::string why;
+  std::lock_guard<std::mutex> lock(g_comm_mu);  // one gather at a time per process: the communicators are shared
   if (!g_rccl.load(&why)) return fail(JADE_ERR_DEVICE, why);
   std::vector<int> devs(ndev);
   for (int i = 0; i < ndev; ++i) devs[i] = scenes[i]->device;
-  std::vector<ncclComm_t> comms(ndev, nullptr);
-  ncclResult_t r = g_rccl.CommInitAll(comms.data(), ndev, devs.data());
-  if (r != ncclSuccess) return fail(JADE_ERR_DEVICE, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r));
-  auto done = [&](int rc) {
-    for (ncclComm_t c : comms)
-      if (c) (void)g_rccl.CommDestroy(c);
-    return rc;
-  };
-  r = g_rccl.GroupStart();
-  for (int i = 1; i < ndev && r == ncclSuccess; ++i) {
+  CommSet* cs = nullptr;
+  for (CommSet& c : g_comm_sets)
+    if (c.devs == devs) cs = &c;
+  if (!cs) {
+    CommSet fresh;
+    fresh.devs = devs;
+    fresh.comms.assign(ndev, nullptr);
+    const ncclResult_t r = g_rccl.CommInitAll(fresh.comms.data(), ndev, devs.data());
+    if (r != ncclSuccess) return fail(JADE_ERR_DEVICE, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r));
+    g_comm_sets.push_back(std::move(fresh));
+    cs = &g_comm_sets.back();
+  }
+  const std::vector<ncclComm_t>& comms = cs->comms;
+  // every exit below this line goes through GroupEnd: an open group would stall the next RCCL user of the process
+  ncclResult_t r = g_rccl.GroupStart();
+  const bool opened = r == ncclSuccess;
+  const char* dev_err = nullptr;
+  for (int i = 1; i < ndev && r == ncclSuccess && !dev_err; ++i) {
     const size_t count = (size_t)scenes[i]->ps.npx * 3;
     if (!count) continue;
-    if (hipSetDevice(scenes[i]->device) != hipSuccess) return done(fail(JADE_ERR_DEVICE, "hipSetDevice failed"));
+    if (hipSetDevice(scenes[i]->device) != hipSuccess) { dev_err = "hipSetDevice failed"; break; }
     r = g_rccl.Send(scenes[i]->b_out_rgb.p, count, ncclFloat, 0, comms[i], scenes[i]->stream);
     if (r != ncclSuccess) break;
-    if (hipSetDevice(scenes[0]->device) != hipSuccess) return done(fail(JADE_ERR_DEVICE, "hipSetDevice failed"));
+    if (hipSetDevice(scenes[0]->device) != hipSuccess) { dev_err = "hipSetDevice failed"; break; }
     r = g_rccl.Recv(dst + off[i], count, ncclFloat, i, comms[0], scenes[0]->stream);
   }
-  const ncclResult_t r2 = g_rccl.GroupEnd();
-  if (r == ncclSuccess) r = r2;
-  if (r != ncclSuccess) return done(fail(JADE_ERR_DEVICE, std::string("RCCL gather: ") + g_rccl.GetErrorString(r)));
-  // rank 0's own share does not travel; then every stream involved must drain before the communicators go
+  if (opened) {
+    const ncclResult_t r2 = g_rccl.GroupEnd();
+    if (r == ncclSuccess) r = r2;
+  }
+  if (dev_err) return fail(JADE_ERR_DEVICE, dev_err);
+  if (r != ncclSuccess) return fail(JADE_ERR_DEVICE, std::string("RCCL gather: ") + g_rccl.GetErrorString(r));
+  // rank 0's own share does not travel; then every stream involved drains before the caller reads the buffer
   hipError_t e = hipSetDevice(scenes[0]->device);
   const size_t own = (size_t)scenes[0]->ps.npx * 12;
   if (e == hipSuccess && own) e = hipMemcpyAsync(dst + off[0], scenes[0]->b_out_rgb.p, own, hipMemcpyDeviceToDevice, scenes[0]->stream);
@@ -1130,8 +1190,8 @@ static int rccl_gather(jade_scene* const* scenes, int ndev, float* dst, const st
     e = hipSetDevice(scenes[i]->device);
     if (e == hipSuccess) e = hipStreamSynchronize(scenes[i]->stream);
   }
-  if (e != hipSuccess) return done(fail(JADE_ERR_DEVICE, std::string("RCCL gather: ") + hipGetErrorString(e)));
-  return done(JADE_OK);
+  if (e != hipSuccess) return fail(JADE_ERR_DEVICE, std::string("RCCL gather: ") + hipGetErrorString(e));
+  return JADE_OK;
 }
 
 extern "C" {
@@ -1308,6 +1368,7 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
   jade_scene* s = new (std::nothrow) jade_scene();
   if (!s) return fail(JADE_ERR_NOMEM, "out of memory");
   s->device = device_id;
+  s->tun.read();
   s->n_emit = d->n_emit;
   s->bvh_depth = depth;
   hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
@@ -1362,11 +1423,8 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
   (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace, JADE_TRACE_BLOCK, 0);
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 8) per_cu = 8;
-  if (const char* e = getenv("JADE_TRACE_BLOCKS_PER_CU")) {  // development: occupancy sweeps (fewer resident blocks than fit)
-    const int v = atoi(e);
-    if (v >= 1 && v < per_cu) per_cu = v;
-  }
-  if (getenv("JADE_LOG_PASSES")) fprintf(stderr, "[jade] k_trace: %d blocks of %d threads per CU, %d CUs\n", per_cu, JADE_TRACE_BLOCK, prop.multiProcessorCount);
+  if (s->tun.trace_blocks_per_cu >= 1 && s->tun.trace_blocks_per_cu < per_cu) per_cu = s->tun.trace_blocks_per_cu;  // development: occupancy sweeps
+  if (s->tun.log_passes) fprintf(stderr, "[jade] k_trace: %d blocks of %d threads per CU, %d CUs\n", per_cu, JADE_TRACE_BLOCK, prop.multiProcessorCount);
   s->trace_blocks = prop.multiProcessorCount * per_cu;
   int light_cu = 0;
   (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&light_cu, k_light, JADE_TRACE_BLOCK, 0);
@@ -1383,15 +1441,18 @@ void jade_scene_destroy(jade_scene* s) {
   delete s;
 }
 
-static int setup_state(jade_scene* s, int npx, int rpp, int nslots) {
+static int setup_state(jade_scene* s, int npx, int rpp, int nslots, int sum_lanes) {
   const int npix = npx * rpp;
   // carve every per-pixel array out of one allocation
   size_t words = 0;
   auto take = [&](size_t n) { size_t o = words; words += (n + 63) & ~(size_t)63; return o; };
   const size_t N = (size_t)npix, K = (size_t)nslots;
-  size_t o_hdr = take(4 * N), o_sum = take(3 * (size_t)JADE_SAMPLE_LANES * npx), o_ctx = take(20 * N), o_orgs = take(4 * N), o_slot = take(8 * K * N);
+  size_t o_hdr = take(4 * N), o_ctx = take(20 * N), o_orgs = take(4 * N), o_slot = take(8 * K * N);
   HIP_TRY(s->b_state.alloc(words * 4));
   HIP_TRY(hipMemsetAsync(s->b_state.p, 0, words * 4, s->stream));
+  // the partial sums are an allocation of their own: they grow if steps add more samples than were announced (grow_sums)
+  HIP_TRY(s->b_sum.alloc((size_t)3 * sum_lanes * npx * 4));
+  HIP_TRY(hipMemsetAsync(s->b_sum.p, 0, (size_t)3 * sum_lanes * npx * 4, s->stream));
   uint32_t* b = s->b_state.as<uint32_t>();
   PathState& P = s->ps;
   P.npix = npix;
@@ -1402,12 +1463,12 @@ static int setup_state(jade_scene* s, int npx, int rpp, int nslots) {
     // from 172 to 142 but de-synchronised records lose coalescing and ray coherence in the
     // heavy passes (2155 vs 2229 Mray/s).  JADE_PIXEL_ROTATE=1 turns it on for experiments.
     const int per = JADE_SAMPLE_LANES / rpp;
-    const char* e = getenv("JADE_PIXEL_ROTATE");
-    P.stride = (e && atoi(e) > 0 && per > 1) ? (npx / per) | 1 : 0;
+    P.stride = (s->tun.pixel_rotate && per > 1) ? (npx / per) | 1 : 0;
   }
   P.nslots = nslots;
   P.hdr = (uint4*)(b + o_hdr);
-  P.sum = (float*)(b + o_sum); P.ctx = (float4*)(b + o_ctx); P.orgs = (float4*)(b + o_orgs);
+  P.sum_lanes = sum_lanes;
+  P.sum = s->b_sum.as<float>(); P.ctx = (float4*)(b + o_ctx); P.orgs = (float4*)(b + o_orgs);
   P.slot = (float4*)(b + o_slot);
   HIP_TRY(s->b_queue.alloc(K * N * 4));
   // b_active[0] doubles as k_light's per-wave hand-over regions: up to 64 records of slack per wave of its grid
@@ -1435,10 +1496,15 @@ int jade_render_begin(jade_scene* s, const jade_render_params* rp) {
   // partial sums come out of the same share), whatever the image share of this GPU: more records = fewer,
   // wider passes.  288 GB is what makes 530 M paths (112 GB) for a full 1080p frame affordable.
   const double bytes_per_record = 4.0 * (30 + 9 * nslots);  // PathState (a slot is two float4) + queue entry + two list entries
-  const double sums_bytes = 12.0 * JADE_SAMPLE_LANES * (double)npx64;
+  // partial sums per pixel: one lane per sample up to JADE_SAMPLE_LANES, never more than the render was announced with
+  // (rounded up to a power of two): a 1-spp 4K frame is 100 MB of sums, not 102 GB
+  int sum_lanes = JADE_SAMPLE_LANES;
+  if (rp->spp > 0)
+    for (sum_lanes = 1; sum_lanes < rp->spp && sum_lanes < JADE_SAMPLE_LANES;) sum_lanes <<= 1;
+  const double sums_bytes = 12.0 * sum_lanes * (double)npx64;
   size_t mem_free = 0, mem_total = 0;
   HIP_TRY(hipMemGetInfo(&mem_free, &mem_total));
-  mem_free += s->b_state.bytes + s->b_queue.bytes + s->b_active[0].bytes + s->b_active[1].bytes;  // ours to reuse
+  mem_free += s->b_state.bytes + s->b_sum.bytes + s->b_queue.bytes + s->b_active[0].bytes + s->b_active[1].bytes;  // ours to reuse
   // the caller's bound (jade_render_params.max_state_bytes) replaces the default share of the free memory
   double state_budget = JADE_RECORD_MEMORY * (double)mem_free;
   if (rp->max_state_bytes) state_budget = std::min((double)rp->max_state_bytes, 0.95 * (double)mem_free);
@@ -1452,9 +1518,9 @@ int jade_render_begin(jade_scene* s, const jade_render_params* rp) {
   while (rpp > 1 && ((double)npx64 * rpp * bytes_per_record > budget || npx64 * rpp * nslots >= ((int64_t)1 << 32) ||
                      npx64 * rpp * 3 >= ((int64_t)1 << 31)))
     rpp >>= 1;
-  if (const char* e = getenv("JADE_RECORDS_PER_PIXEL")) {  // test hook: results must not depend on it
-    int v = atoi(e);
-    if (v >= 1 && v <= JADE_SAMPLE_LANES && (v & (v - 1)) == 0) rpp = v;
+  if (const int v = s->tun.records_per_pixel; v >= 1 && v <= JADE_SAMPLE_LANES && (v & (v - 1)) == 0) {  // test hook: results must not depend on it
+    rpp = v;
+    if (sum_lanes < rpp) sum_lanes = rpp;
   }
   const int64_t npix64 = npx64 * rpp;
   if (npix64 * nslots >= ((int64_t)1 << 32) || npix64 * 3 >= ((int64_t)1 << 31))
@@ -1462,9 +1528,9 @@ int jade_render_begin(jade_scene* s, const jade_render_params* rp) {
   if (sums_bytes + (double)npix64 * bytes_per_record > (rp->max_state_bytes ? std::max(state_budget, 0.0) : 0.95 * (double)mem_free))
     return fail(JADE_ERR_NOMEM, rp->max_state_bytes ? "frame does not fit max_state_bytes (partial sums + one record per pixel)"
                                                     : "frame does not fit the device memory (partial sums + one record per pixel)");
-  if (getenv("JADE_LOG_PASSES"))
-    fprintf(stderr, "[jade] %lld pixels x %d records, %.1f GB of path state + %.1f GB of partial sums (%.0f GB free)\n", (long long)npx64,
-            rpp, npix64 * bytes_per_record / 1e9, sums_bytes / 1e9, mem_free / 1e9);
+  if (s->tun.log_passes)
+    fprintf(stderr, "[jade] %lld pixels x %d records, %.1f GB of path state + %.1f GB of partial sums in %d lanes (%.0f GB free)\n", (long long)npx64,
+            rpp, npix64 * bytes_per_record / 1e9, 12.0 * sum_lanes * (double)npx64 / 1e9, sum_lanes, mem_free / 1e9);
   s->have_rp = false;
   s->rp = *rp;
   RenderConst& R = s->rc;
@@ -1477,7 +1543,7 @@ int jade_render_begin(jade_scene* s, const jade_render_params* rp) {
   s->spp_done = 0;
   s->tail_pending = false;
   if (npix64 == 0) { s->ps.npix = 0; s->ps.npx = 0; s->have_rp = true; return JADE_OK; }
-  int rc = setup_state(s, (int)npx64, rpp, nslots);
+  int rc = setup_state(s, (int)npx64, rpp, nslots, sum_lanes);
   if (rc) return rc;
   memcpy(s->ps.eye, rp->eye, sizeof s->ps.eye);
   HIP_TRY(upload(s->b_tiles, s->tile_ids.data(), s->tile_ids.size(), s->stream));
@@ -1532,9 +1598,9 @@ static int run_passes(jade_scene* s, int64_t from_spp, uint32_t target_spp, bool
   // While at least a quarter of the records are active, a pass is k_shade_lean over all records
   // (record order, no list) followed by k_shade over what it handed over; below that, k_shade alone
   // over the active list, which k_arm rebuilds once at the switch.  JADE_SHADE_SPLIT=0: always the list.
-  const bool split_ok = !(getenv("JADE_SHADE_SPLIT") && atoi(getenv("JADE_SHADE_SPLIT")) == 0);
+  const bool split_ok = s->tun.shade_split;
   // JADE_FUSED=0: the first pass as shade / trace passes too (k_shade_lean), the schedule before k_light existed
-  const bool fused = split_ok && !(getenv("JADE_FUSED") && atoi(getenv("JADE_FUSED")) == 0);
+  const bool fused = s->tun.fused;
   // the records with work in this step: all of them when the step gives every record a sample (k_light then walks the
   // records itself); otherwise - a flush, a step of fewer samples than records per pixel - k_arm lists and counts them
   uint32_t host_ctl[3] = {0, 0, 0};
@@ -1552,17 +1618,17 @@ static int run_passes(jade_scene* s, int64_t from_spp, uint32_t target_spp, bool
   }
   const uint32_t n_armed = n_active;  // records with work at the start of this call
   int cur = 0, pass_no = 0;
-  const bool log_passes = getenv("JADE_LOG_PASSES") != nullptr;
+  const bool log_passes = s->tun.log_passes;
   bool have_list = true;  // b_active[cur] lists the active records
   bool light_timed = false;
   float shade_ms = 0, lean_ms = 0;
-  const double carry_frac = getenv("JADE_CARRY_FRACTION") ? atof(getenv("JADE_CARRY_FRACTION")) : JADE_CARRY_FRACTION;
+  const double carry_frac = s->tun.carry_frac;
   auto carry_now = [&](uint32_t act) {
     return may_carry && ((act < JADE_CARRY_RECORDS && (uint64_t)act * 1024 < (uint64_t)n_armed) ||
                          (carry_frac > 0 && (double)act < carry_frac * (double)n_armed));
   };
   // JADE_BATCH=0: the host follows every pass (the schedule before batching existed)
-  const bool batching = !(getenv("JADE_BATCH") && atoi(getenv("JADE_BATCH")) == 0);
+  const bool batching = s->tun.batching;
   bool closed_by_batch = false;  // the wait at the end of a batch was also the wait for the end of the step
   while (n_active) {
     const bool lean_mode = split_ok && (uint64_t)n_active * 4 >= (uint64_t)npix;
@@ -1829,14 +1895,50 @@ static int advance(jade_scene* s, int64_t from0, bool may_carry, jade_stats* st)
   return JADE_OK;
 }
 
+// The steps add more samples than jade_render_begin was told of: more lanes of partial sums (jade_rt.h,
+// JADE_Q_SUM_LANES).  Lane l of plane c sits at (c * lanes + l) * npx, so the planes move apart; the new lanes are +0.
+static int grow_sums(jade_scene* s, int64_t spp_total) {
+  PathState& P = s->ps;
+  int lanes = P.sum_lanes;
+  while (lanes < JADE_SAMPLE_LANES && lanes < spp_total) lanes <<= 1;
+  if (lanes == P.sum_lanes) return JADE_OK;
+  DevBuf nb;
+  const size_t plane_old = (size_t)P.sum_lanes * P.npx * 4, plane_new = (size_t)lanes * P.npx * 4;
+  HIP_TRY(nb.alloc(3 * plane_new));
+  HIP_TRY(hipMemsetAsync(nb.p, 0, 3 * plane_new, s->stream));
+  for (int c = 0; c < 3; ++c)
+    HIP_TRY(hipMemcpyAsync((char*)nb.p + c * plane_new, (const char*)s->b_sum.p + c * plane_old, plane_old, hipMemcpyDeviceToDevice, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  std::swap(s->b_sum.p, nb.p);
+  std::swap(s->b_sum.bytes, nb.bytes);
+  P.sum = s->b_sum.as<float>();
+  P.sum_lanes = lanes;
+  return JADE_OK;
+}
+
+int jade_render_query(jade_scene* s, int what, int64_t* value) {
+  if (!s || !value || !s->have_rp) return fail(JADE_ERR_INVALID, "jade_render_begin not called");
+  switch (what) {
+    case JADE_Q_RECORDS_PER_PIXEL: *value = s->ps.npix ? s->ps.rpp : 0; return JADE_OK;
+    case JADE_Q_STATE_BYTES:
+      *value = s->ps.npix ? (int64_t)(s->b_state.bytes + s->b_sum.bytes + s->b_queue.bytes + s->b_active[0].bytes + s->b_active[1].bytes +
+                                      s->b_wavecnt.bytes + s->b_spill.bytes + s->b_sortkey.bytes + s->b_sorttmp.bytes)
+                          : 0;
+      return JADE_OK;
+    case JADE_Q_SUM_LANES: *value = s->ps.npix ? s->ps.sum_lanes : 0; return JADE_OK;
+    default: return fail(JADE_ERR_INVALID, "unknown query");
+  }
+}
+
 int jade_render_step(jade_scene* s, int32_t spp, jade_stats* st) {
   if (!s || !s->have_rp) return fail(JADE_ERR_INVALID, "jade_render_begin not called");
   if (spp < 0) return fail(JADE_ERR_INVALID, "negative spp");
   HIP_TRY(hipSetDevice(s->device));
   s->spp_done += spp;
   if (s->ps.npix == 0 || spp == 0) return JADE_OK;
-  const bool carry = !(getenv("JADE_CARRY") && atoi(getenv("JADE_CARRY")) == 0);
-  return advance(s, s->spp_done - spp, carry, st);
+  if (s->spp_done > s->ps.sum_lanes && s->ps.sum_lanes < JADE_SAMPLE_LANES)
+    if (int rc = grow_sums(s, s->spp_done)) return rc;
+  return advance(s, s->spp_done - spp, s->tun.carry, st);
 }
 
 int jade_render_flush(jade_scene* s, jade_stats* st) {
@@ -2003,7 +2105,7 @@ int jade_render_multi(jade_scene* const* scenes, int ndev, const jade_render_par
   for (int i = 0; i < ndev; ++i)
     for (int j = 0; j < i; ++j) distinct = distinct && scenes[i]->device != scenes[j]->device;
   // JADE_FORCE_RCCL=1 (tests): take the RCCL path for a single share too - library load, communicator, empty group
-  if (distinct && (ndev > 1 || getenv("JADE_FORCE_RCCL"))) {
+  if (distinct && (ndev > 1 || s0->tun.force_rccl)) {
     if (int rc = rccl_gather(scenes, ndev, gather.as<float>(), off)) return rc;
   } else {
     for (int i = 0; i < ndev; ++i) {
@@ -2040,6 +2142,8 @@ int jade_render_multi(jade_scene* const* scenes, int ndev, const jade_render_par
       st->rays_primary += sts[i].rays_primary; st->rays_secondary += sts[i].rays_secondary;
       st->rays_shadow += sts[i].rays_shadow; st->rays_env += sts[i].rays_env; st->rays_indirect += sts[i].rays_indirect;
       st->rays_mirror += sts[i].rays_mirror; st->rays_refract += sts[i].rays_refract; st->host_syncs += sts[i].host_syncs;
+      st->rays_inline += sts[i].rays_inline;
+      st->light_ms = std::max(st->light_ms, sts[i].light_ms);
       st->nodes_visited += sts[i].nodes_visited; st->tris_tested += sts[i].tris_tested;
       st->shaded_hits += sts[i].shaded_hits; st->samples += sts[i].samples;
       st->kernel_ms = std::max(st->kernel_ms, sts[i].kernel_ms);  // the shares run concurrently

@@ -70,6 +70,11 @@ struct jade_scene {
   int have_rp;
   float* sum;       /* [JADE_SAMPLE_LANES][pixel][3] partial radiance sums (untouched lanes stay unmapped) */
   int64_t spp_done;
+  /* checker-only: jade_oracle_set_tile_filter() restricts a render to listed tiles of the caller's partition */
+  uint8_t* tile_keep; /* one byte per tile id (ty * tiles_x + tx), NULL = no filter */
+  int32_t tile_keep_n;
+  int32_t* sum_slot;  /* with a filter: pixel -> its slot in the (compact) sums, -1 = not rendered; NULL = identity */
+  size_t sum_pixels;  /* pixels the sums hold per lane */
 };
 
 typedef struct {
@@ -917,12 +922,42 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
 void jade_scene_destroy(jade_scene* s) {
   if (!s) return;
   free(s->tris); free(s->nodes); free(s->emit); free(s->mapping);
-  free(s->prefix); free(s->segs); free(s->env); free(s->sum);
+  free(s->prefix); free(s->segs); free(s->env); free(s->sum); free(s->tile_keep); free(s->sum_slot);
   free(s);
 }
 
-static int owns_pixel(const jade_render_params* rp, int x, int y) {
-  return (x / JADE_TILE_SIZE + y / JADE_TILE_SIZE) % rp->tile_nranks == rp->tile_rank;
+static int owns_pixel_s(const jade_scene* s, int x, int y) {
+  const jade_render_params* rp = &s->rp;
+  if ((x / JADE_TILE_SIZE + y / JADE_TILE_SIZE) % rp->tile_nranks != rp->tile_rank) return 0;
+  if (s->tile_keep) {
+    const int tiles_x = (rp->width + JADE_TILE_SIZE - 1) / JADE_TILE_SIZE;
+    const int tid = (y / JADE_TILE_SIZE) * tiles_x + x / JADE_TILE_SIZE;
+    return tid < s->tile_keep_n && s->tile_keep[tid];
+  }
+  return 1;
+}
+
+/* Checker-only extension (NOT part of jade_rt.h; the HIP module has no such entry point): restrict the renders that
+ * follow to the listed 16x16 tiles (id = ty * tiles_x + tx, tiles_x = ceil(width / 16)) of whatever partition the
+ * params name.  bench.py's parity_check and the full-size parity tests use it to let the oracle render a few tiles of
+ * a 1920x1080 / 3840x2160 frame at the benchmark's full sample count in seconds (samples are independent work items,
+ * PathTrace.cu:1418-1474: a pixel's value does not depend on which other pixels are rendered).  n = 0 clears it. */
+int jade_oracle_set_tile_filter(jade_scene* s, const int32_t* tile_ids, int32_t n) {
+  if (!s || n < 0 || (n > 0 && !tile_ids)) return fail(JADE_ERR_INVALID, "bad tile filter");
+  free(s->tile_keep);
+  s->tile_keep = NULL;
+  s->tile_keep_n = 0;
+  if (n == 0) return JADE_OK;
+  int32_t mx = -1;
+  for (int i = 0; i < n; ++i) {
+    if (tile_ids[i] < 0) return fail(JADE_ERR_INVALID, "negative tile id");
+    if (tile_ids[i] > mx) mx = tile_ids[i];
+  }
+  s->tile_keep = (uint8_t*)calloc((size_t)mx + 1, 1);
+  if (!s->tile_keep) return fail(JADE_ERR_NOMEM, "out of memory");
+  s->tile_keep_n = mx + 1;
+  for (int i = 0; i < n; ++i) s->tile_keep[tile_ids[i]] = 1;
+  return JADE_OK;
 }
 
 int jade_owned_tile_count(int32_t width, int32_t height, int32_t rank, int32_t nranks) {
@@ -940,9 +975,21 @@ int jade_render_begin(jade_scene* s, const jade_render_params* rp) {
     return fail(JADE_ERR_INVALID, "bad image size or tile partition");
   size_t np = (size_t)rp->width * rp->height;
   free(s->sum);
-  s->sum = (float*)calloc(np * 3 * JADE_SAMPLE_LANES, sizeof(float));
-  if (!s->sum) return fail(JADE_ERR_NOMEM, "out of memory");
+  s->sum = NULL;
+  free(s->sum_slot);
+  s->sum_slot = NULL;
   s->rp = *rp;
+  s->sum_pixels = np;
+  if (s->tile_keep) { /* sums for the kept pixels only: a few tiles of a 4K frame must not reserve 100 GB of address space */
+    s->sum_slot = (int32_t*)malloc(np * sizeof(int32_t));
+    if (!s->sum_slot) return fail(JADE_ERR_NOMEM, "out of memory");
+    size_t k = 0;
+    for (int y = 0; y < rp->height; ++y)
+      for (int x = 0; x < rp->width; ++x) s->sum_slot[(size_t)y * rp->width + x] = owns_pixel_s(s, x, y) ? (int32_t)k++ : -1;
+    s->sum_pixels = k ? k : 1;
+  }
+  s->sum = (float*)calloc(s->sum_pixels * 3 * JADE_SAMPLE_LANES, sizeof(float));
+  if (!s->sum) return fail(JADE_ERR_NOMEM, "out of memory");
   s->have_rp = 1;
   s->spp_done = 0;
   return JADE_OK;
@@ -966,9 +1013,9 @@ static void* worker(void* p) {
     int y = __sync_fetch_and_add(a->next_row, 1);
     if (y >= rp->height) break;
     for (int x = 0; x < rp->width; ++x) {
-      if (!owns_pixel(rp, x, y)) continue;
-      size_t pi = (size_t)y * rp->width + x;
-      const size_t np = (size_t)rp->width * rp->height;
+      if (!owns_pixel_s(s, x, y)) continue;
+      const size_t pi = s->sum_slot ? (size_t)s->sum_slot[(size_t)y * rp->width + x] : (size_t)y * rp->width + x;
+      const size_t np = s->sum_pixels;
       for (int i = 0; i < a->spp; ++i) {
         int64_t sidx = a->first_sample + i;
         uint32_t rng = jade_rng_seed((uint32_t)x, (uint32_t)y, rp->frame + (uint32_t)sidx);
@@ -1050,9 +1097,10 @@ int jade_render_resolve_ex(jade_scene* s, int tonemap, float limit, float* out_r
   float inv = (float)(1.0 / (double)s->spp_done);
   for (int y = 0; y < rp->height; ++y)
     for (int x = 0; x < rp->width; ++x) {
-      if (!owns_pixel(rp, x, y)) continue;
-      size_t pi = (size_t)y * rp->width + x;
-      const size_t np = (size_t)rp->width * rp->height;
+      if (!owns_pixel_s(s, x, y)) continue;
+      const size_t px = (size_t)y * rp->width + x; /* in the caller's frame */
+      const size_t pi = s->sum_slot ? (size_t)s->sum_slot[px] : px;
+      const size_t np = s->sum_pixels;
       jvec3 tot = jv(s->sum[3 * pi], s->sum[3 * pi + 1], s->sum[3 * pi + 2]);
       /* lanes >= spp_done were never written: they are +0.0, and adding +0.0 any number of times is
        * adding it once (it only turns a -0.0 total into +0.0) - the untouched pages stay unmapped */
@@ -1063,8 +1111,8 @@ int jade_render_resolve_ex(jade_scene* s, int tonemap, float limit, float* out_r
       }
       if (used < JADE_SAMPLE_LANES) tot = jv_add(tot, jv(0.0f, 0.0f, 0.0f));
       jvec3 m = jv(tot.x * inv, tot.y * inv, tot.z * inv);
-      if (out_rgb) { out_rgb[3 * pi] = m.x; out_rgb[3 * pi + 1] = m.y; out_rgb[3 * pi + 2] = m.z; }
-      if (out_bgr8) tonemap_pack(m, tonemap, limit, out_bgr8 + 3 * pi);
+      if (out_rgb) { out_rgb[3 * px] = m.x; out_rgb[3 * px + 1] = m.y; out_rgb[3 * px + 2] = m.z; }
+      if (out_bgr8) tonemap_pack(m, tonemap, limit, out_bgr8 + 3 * px);
     }
   return JADE_OK;
 }
@@ -1090,6 +1138,16 @@ int jade_render_multi(jade_scene* const* scenes, int ndev, const jade_render_par
     if (rc) return rc;
   }
   return JADE_OK;
+}
+
+int jade_render_query(jade_scene* s, int what, int64_t* value) {
+  if (!s || !value || !s->have_rp) return fail(JADE_ERR_INVALID, "jade_render_begin not called");
+  switch (what) {
+    case JADE_Q_RECORDS_PER_PIXEL: *value = 1; return JADE_OK;
+    case JADE_Q_STATE_BYTES: *value = (int64_t)(s->sum_pixels * 3 * JADE_SAMPLE_LANES * sizeof(float)); return JADE_OK;
+    case JADE_Q_SUM_LANES: *value = JADE_SAMPLE_LANES; return JADE_OK;
+    default: return fail(JADE_ERR_INVALID, "unknown query");
+  }
 }
 
 int jade_render_resolve_tiles_device(jade_scene* s, float* dev_tiles, void* stream) {

@@ -146,3 +146,47 @@ def test_ploc_tree_quality_against_the_host_sah_tree(hip):
     assert np.array_equal(hits["sah"].view(np.uint32), hits["ploc"].view(np.uint32))   # the closest hit does not depend on the tree
     assert cost["ploc"][0] <= 1.1 * cost["sah"][0] and cost["ploc"][1] <= 1.1 * cost["sah"][1]
     assert cost["ploc"][0] < 0.8 * cost["lbvh"][0] and cost["ploc"][1] < 0.8 * cost["lbvh"][1]
+
+
+def test_ploc_on_regular_and_duplicated_geometry(oracle, hip):
+    """Rows of clusters whose unions all have the same area - a ribbon of equal triangles, instanced duplicates - used to
+    chain under PLOC's tie rule (every cluster chose its lower neighbour, one mutual pair merged per round: 600 identical
+    triangles took 599 rounds and the build gave up after 256).  The rule now pairs (2k, 2k+1) on exact ties; the trees
+    stay shallow enough for the traversal stack and trace bit-exactly like the oracle and like a brute-force scan."""
+    from jaderaytracerendering_amd import host as H
+    tri = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    cases = {}
+    # 600 copies of one triangle at the same place
+    cases["duplicates"] = np.tile(tri, (600, 1))
+    # a strip of 2000 unit triangles along x
+    k = np.arange(1000, dtype=np.float32)[:, None, None]
+    lower = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)[None] + k * np.array([1, 0, 0], np.float32)
+    upper = np.array([[1, 0, 0], [1, 1, 0], [0, 1, 0]], np.float32)[None] + k * np.array([1, 0, 0], np.float32)
+    cases["strip"] = np.stack([lower, upper], 1).reshape(-1, 3)
+    # a small mesh instanced 8 times at the same place
+    cases["instanced"] = np.tile(np.random.default_rng(3).random((3 * 50, 3)).astype(np.float32), (8, 1))
+    for name, v in cases.items():
+        bb = J.SceneBuilder()
+        bb.add_mesh(v, np.arange(len(v)).reshape(-1, 3), H.material())
+        bb.set_env_sky(16, 8)
+        hs, ms = bb.build_device_bvh(hip, "ploc", leaf_size=3)
+        flat = bb.build(10 ** 9)
+        depth = _check_invariants(hs)
+        print(f"ploc {name}: {len(v) // 3} triangles, depth {depth}, {ms:.2f} ms")
+        assert depth <= 40
+        rng = np.random.default_rng(9)
+        n = 5000
+        lo, hi = v.min(0), v.max(0)
+        o = (rng.random((n, 3)) * (hi - lo + 1) + lo - 0.5).astype(np.float32)
+        o[:, 2] = 3.0
+        d = np.tile(np.array([[0.01, 0.02, -1.0]], np.float32), (n, 1)) + rng.normal(size=(n, 3)).astype(np.float32) * 0.05
+        skip = np.full(n, -1, np.int32)
+        with oracle.scene(hs) as so, oracle.scene(flat) as sf, hip.scene(hs) as sh:
+            io, do, po, st_o = so.trace_rays(o, d, skip)
+            i_f, df, _, _ = sf.trace_rays(o, d, skip)
+            ih, dh, ph, st_h = sh.trace_rays(o, d, skip)
+        h = io >= 0
+        assert h.sum() > 50 and np.array_equal(h, i_f >= 0)
+        assert np.array_equal(do.view(np.uint32), dh.view(np.uint32)) and np.array_equal(io, ih)
+        assert np.array_equal(do[h].view(np.uint32), df[h].view(np.uint32))
+        assert (st_o.nodes_visited, st_o.tris_tested) == (st_h.nodes_visited, st_h.tris_tested)
