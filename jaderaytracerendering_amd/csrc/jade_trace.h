@@ -42,6 +42,57 @@ struct TraceHit {
 #define JADE_ABLATE_LOAD 0
 #endif
 
+// Development profile (where inside a unit of work do a wave's clocks go?): -DJADE_TRACE_PROFILE=1 brackets the
+// pieces of k_trace's loop with s_memtime and FORCES the wait for a piece's loads inside that piece (s_waitcnt), so that
+// every lap is "issue ... data arrived".  That serialises what the product build may overlap and costs ~10 % (the guide's
+// figure for stamps): the laps are a breakdown, not a timing.  Results: tools/trace_profile.py -> profiles/.  Off = no code.
+#ifndef JADE_TRACE_PROFILE
+#define JADE_TRACE_PROFILE 0
+#endif
+enum {
+  PL_TOP = 0,      // loop top: has my ray ended (LDS), ballot of idle lanes
+  PL_WRITEBACK,    // results of ended rays -> memory (walk_result re-reads the winning record)
+  PL_REFILL,       // claim queue entries, load the rays, walk_begin
+  PL_PICK,         // iterate(): the ballots that choose the kind of work
+  PL_WALK_LOAD,    // walk unit: LDS tree-top read + node record gather, until the data is in registers
+  PL_WALK_MATH,    // walk unit: slab tests, decisions, stack push / pop (LDS)
+  PL_WALK_RING,    // walk unit: leaves met -> the wave's ring
+  PL_TEST_POP,     // test unit: lanes without an item take the next ones from the ring
+  PL_TEST_LOAD,    // test unit: pair record gather, until the data is in registers
+  PL_TEST_RAY,     // test unit: the owner's ray through ds_bpermute
+  PL_TEST_MATH,    // test unit: the packed inside test, finished-leaf counter
+  PL_TEST_CAND,    // test unit: candidates -> second ring
+  PL_RESOLVE,      // resolve_pass: barycentric solve of <= 64 candidates, best-hit update
+  PL_N_LAPS,
+  PC_ITER = PL_N_LAPS, PC_WALK_UNITS, PC_TEST_UNITS, PC_RESOLVES, PC_REFILLS, PC_WAVES, PC_WALK_LANES, PC_TEST_LANES,
+  PL_N
+};
+#if JADE_TRACE_PROFILE
+struct TraceProf {
+  unsigned long long last;
+  unsigned long long v[PL_N];
+  __device__ __forceinline__ void begin() {
+    for (int i = 0; i < PL_N; ++i) v[i] = 0;
+    last = __builtin_amdgcn_s_memtime();
+  }
+  __device__ __forceinline__ void lap(int i) {
+    const unsigned long long now = __builtin_amdgcn_s_memtime();
+    v[i] += now - last;
+    last = now;
+  }
+  __device__ __forceinline__ void count(int i, unsigned long long n = 1) { v[i] += n; }
+  static __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+};
+#define PROF_LAP(pr, i) (pr).lap(i)
+#define PROF_COUNT(pr, i, n) (pr).count(i, n)
+#define PROF_DRAIN() TraceProf::drain()
+#else
+struct TraceProf {};
+#define PROF_LAP(pr, i) ((void)0)
+#define PROF_COUNT(pr, i, n) ((void)0)
+#define PROF_DRAIN() ((void)0)
+#endif
+
 // A lane's column of LDS words, word k of lane t at byte  k * JADE_COL_STRIDE + 4 t  of the block's column array
 // (bank-conflict free): words [0, JADE_LDS_STACK) are the traversal stack, then the leaf FIFO, then the JADE_LDS_STATE
 // words that hold the parts of the ray state the triangle test does not read (see RayState).
@@ -237,10 +288,13 @@ static __device__ __forceinline__ jvec3 ray_hit_point(const LdsStack& stk) {
 // The core shared by the two forms of the walk (a FIFO of leaf cursors per lane: k_light; one queue of leaves per wave:
 // k_trace).  W_INV / W_DUMMY: where the column keeps 1/d and the dummy word.  room: a leaf met now can be taken.  Returns
 // the leaf met (0 = none); cur and sp advance.
-template <bool GENERAL, int W_INV, int W_DUMMY, int TOPN>
-static __device__ __forceinline__ uint32_t node_core(uint32_t& cur_io, uint32_t& sp_io, const RayOD& od, const DevScene& S, const LdsStack& stk, bool room,
-                                                     uint32_t& vcnt, const jvec3* inv_reg = nullptr) {
-  const uint32_t cur = cur_io;
+struct NodeRec {  // a node record in registers: the children's boxes (interleaved, jade_device.h) and their references
+  float4 a, b, c;
+  uint2 rf;
+};
+// the record of the node `cur` stands at (a leaf reference reads record 0 and ignores it)
+template <int TOPN>
+static __device__ __forceinline__ NodeRec node_fetch(uint32_t cur, const DevScene& S, const LdsStack& stk) {
   const bool is_leaf = (int32_t)cur < 0;
   const uint32_t node = is_leaf ? 0u : cur;  // such a lane reads record 0 and ignores it
   float4 a, b, c;
@@ -294,6 +348,21 @@ static __device__ __forceinline__ uint32_t node_core(uint32_t& cur_io, uint32_t&
     rf = *reinterpret_cast<const uint2*>(nd + 3);
   }
 #endif
+  NodeRec nr;
+  nr.a = a;
+  nr.b = b;
+  nr.c = c;
+  nr.rf = rf;
+  return nr;
+}
+// the slab tests and what follows from them (see above node_fetch)
+template <bool GENERAL, int W_INV, int W_DUMMY>
+static __device__ __forceinline__ uint32_t node_decide(const NodeRec& nr, uint32_t& cur_io, uint32_t& sp_io, const RayOD& od, const LdsStack& stk, bool room,
+                                                       uint32_t& vcnt, const jvec3* inv_reg = nullptr) {
+  const uint32_t cur = cur_io;
+  const bool is_leaf = (int32_t)cur < 0;
+  const float4 a = nr.a, b = nr.b, c = nr.c;
+  const uint2 rf = nr.rf;
   // 1/d: from the caller's registers (k_trace, which has them to spare at 4 waves per SIMD) or from the lane's column
   const jvec3 inv = inv_reg ? *inv_reg : jv(lds_getf(stk, W_INV), lds_getf(stk, W_INV + 1), lds_getf(stk, W_INV + 2));
   float d1, d2;
@@ -345,6 +414,12 @@ static __device__ __forceinline__ uint32_t node_core(uint32_t& cur_io, uint32_t&
   sp_io = do_pop ? sp1 : sp;
   cur_io = need_pop ? (do_pop ? top : JADE_REF_NONE) : next;
   return leafv;
+}
+template <bool GENERAL, int W_INV, int W_DUMMY, int TOPN>
+static __device__ __forceinline__ uint32_t node_core(uint32_t& cur_io, uint32_t& sp_io, const RayOD& od, const DevScene& S, const LdsStack& stk, bool room,
+                                                     uint32_t& vcnt, const jvec3* inv_reg = nullptr) {
+  const NodeRec nr = node_fetch<TOPN>(cur_io, S, stk);
+  return node_decide<GENERAL, W_INV, W_DUMMY>(nr, cur_io, sp_io, od, stk, room, vcnt, inv_reg);
 }
 
 // The walk with a FIFO of leaf cursors per lane (k_light): one unit for a lane with ray_can_walk.
@@ -694,12 +769,19 @@ struct WaveTrace {
   // holds a ray), or triangle tests, for as many lanes as there are leaves waiting.  The kind that advances more lanes per
   // instruction issued runs; the walk needs room for the 64 leaves one unit of it can push.  When every ray in flight only
   // waits for candidates (fewer than a batch), they are resolved.
-  __device__ __forceinline__ void iterate(WalkState& r, bool active, const DevScene& S, const LdsStack& stk, uint32_t& vcnt, uint32_t& tcnt) {
+  __device__ __forceinline__ void iterate(WalkState& r, bool active, const DevScene& S, const LdsStack& stk, uint32_t& vcnt, uint32_t& tcnt, TraceProf& pr) {
     const int nw = __popcll(__ballot(active && r.cur != JADE_REF_NONE));
     const uint32_t n_items = q_count + (uint32_t)__popcll(__ballot(item_leaf != 0));
     const uint32_t nt = n_items < 64u ? n_items : 64u;
+    PROF_COUNT(pr, PC_ITER, 1);
+    PROF_LAP(pr, PL_PICK);
     if (nw == 0 && n_items == 0) {
-      if (h_count != 0) resolve_pass(r, S, stk);
+      if (h_count != 0) {
+        resolve_pass(r, S, stk);
+        PROF_DRAIN();
+        PROF_COUNT(pr, PC_RESOLVES, 1);
+        PROF_LAP(pr, PL_RESOLVE);
+      }
       return;
     }
     if (q_count <= JADE_WQ - 64 && nw > 0 && JADE_COST_TRI * (uint32_t)nw >= JADE_COST_NODE * nt) {
@@ -709,11 +791,30 @@ struct WaveTrace {
         if (q_count > JADE_WQ - 64) break;
         const bool go = active && r.cur != JADE_REF_NONE;
         uint32_t leafv = 0;
+#if JADE_TRACE_PROFILE
+        {  // the walk unit in two laps: the record's fetch (until the data is in registers), then everything else
+          PROF_COUNT(pr, PC_WALK_UNITS, 1);
+          PROF_COUNT(pr, PC_WALK_LANES, (unsigned long long)__popcll(__ballot(go)));
+          NodeRec nr;
+          if (go) nr = node_fetch<JADE_TRACE_TOP_NODES>(r.cur, S, stk);
+          PROF_DRAIN();
+          PROF_LAP(pr, PL_WALK_LOAD);
+          if (general) {
+            if (go) leafv = node_decide<true, 0, TW_DUMMY>(nr, r.cur, r.sp, r.od, stk, true, vcnt, &r.inv);
+          } else {
+            if (go) leafv = node_decide<false, 0, TW_DUMMY>(nr, r.cur, r.sp, r.od, stk, true, vcnt, &r.inv);
+          }
+          leafv = (leafv & 15u) != 0 ? leafv : 0u;
+          PROF_DRAIN();
+          PROF_LAP(pr, PL_WALK_MATH);
+        }
+#else
         if (general) {
           if (go) leafv = walk_step<true>(r, S, stk, vcnt);
         } else {
           if (go) leafv = walk_step<false>(r, S, stk, vcnt);
         }
+#endif
         // the leaves met by this unit, in lane order (any order would do: a leaf's place among its ray's leaves is its
         // sequence number)
         const unsigned long long m = __ballot(leafv != 0);
@@ -724,6 +825,8 @@ struct WaveTrace {
           }
           q_count += (uint32_t)__popcll(m);
         }
+        PROF_DRAIN();
+        PROF_LAP(pr, PL_WALK_RING);
       }
     } else {
 #pragma nounroll
@@ -739,16 +842,26 @@ struct WaveTrace {
           q_count -= npop;
         }
         const bool go = item_leaf != 0;
+        PROF_DRAIN();
+        PROF_LAP(pr, PL_TEST_POP);
         if (__ballot(go) == 0ull) break;
+        PROF_COUNT(pr, PC_TEST_UNITS, 1);
+        PROF_COUNT(pr, PC_TEST_LANES, (unsigned long long)__popcll(__ballot(go)));
         // the record first (it depends on the item alone), then the ray the item belongs to
         const uint32_t off = item_leaf & 0x7ffffff0u;
         PairRec rec;
         if (go) rec = pair_load(S, off);
+        PROF_DRAIN();
+        PROF_LAP(pr, PL_TEST_LOAD);
         const int owner = (int)(item_meta & 63u);
         const RayOD od = ray_of(r, owner);
         const uint32_t skip = (uint32_t)__shfl((int)r.skipx, owner, 64) & 0x7fffffffu;
+        PROF_DRAIN();
+        PROF_LAP(pr, PL_TEST_RAY);
         bool in_a = false, in_b = false;
         if (go) test_step(item_leaf, item_meta, od, skip, rec, stk, lane, tcnt, in_a, in_b);
+        PROF_DRAIN();
+        PROF_LAP(pr, PL_TEST_MATH);
         // candidates (the origin projects into the triangle) are resolved later, many at a time
         const unsigned long long ma = __ballot(in_a), mb = __ballot(in_b);
         if (ma != 0ull) {
@@ -761,8 +874,15 @@ struct WaveTrace {
           if (in_b) lds_st64(hq + ((h_head + h_count + rank_in(mb)) & (JADE_HQ - 1u)) * 8u, off | 1u, item_meta);
           h_count += (uint32_t)__popcll(mb);
         }
+        PROF_DRAIN();
+        PROF_LAP(pr, PL_TEST_CAND);
       }
-      if (h_count >= JADE_HQ_BATCH) resolve_pass(r, S, stk);
+      if (h_count >= JADE_HQ_BATCH) {
+        resolve_pass(r, S, stk);
+        PROF_DRAIN();
+        PROF_COUNT(pr, PC_RESOLVES, 1);
+        PROF_LAP(pr, PL_RESOLVE);
+      }
     }
   }
 };

@@ -980,7 +980,7 @@ int jade_render_begin(jade_scene* s, const jade_render_params* rp) {
   s->sum_slot = NULL;
   s->rp = *rp;
   s->sum_pixels = np;
-  if (s->tile_keep) { /* sums for the kept pixels only: a few tiles of a 4K frame must not reserve 100 GB of address space */
+  if (s->tile_keep || rp->tile_nranks > 1) { /* sums for the rendered pixels only: a few tiles of a 4K frame must not reserve 100 GB of address space */
     s->sum_slot = (int32_t*)malloc(np * sizeof(int32_t));
     if (!s->sum_slot) return fail(JADE_ERR_NOMEM, "out of memory");
     size_t k = 0;

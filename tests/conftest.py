@@ -96,3 +96,40 @@ def fpm():
     lib.t_seed.restype = ctypes.c_uint32
     lib.t_seed.argtypes = [ctypes.c_uint32] * 3
     return lib
+
+
+def object_tiles(hs, cfg, width, height, obj=0):
+    """Tile ids (ty * tiles_x + tx) the vertices of object `obj` project into, with the number of vertices per tile: the
+    camera mapping of PathTrace.cu:1430-1437 inverted (dir ~ M . (lx * W/H, ly, -1.5, 0), lx = -1 + 2/W (x + u - 0.5))."""
+    v = hs.vertices()[hs.tri_i32()[:, 0] == obj].reshape(-1, 3).astype(np.float64)
+    m = np.asarray(list(cfg.camera), np.float64).reshape(4, 4)  # [col][row]
+    rel = v - np.asarray(list(cfg.eye), np.float64)
+    a, b, c = rel @ m[0, :3], rel @ m[1, :3], rel @ m[2, :3]
+    front = c < 0
+    s = -1.5 / c[front]
+    lx, ly = a[front] * s / (width / height), b[front] * s
+    x, y = np.floor((lx + 1) * width / 2), np.floor((ly + 1) * height / 2)
+    ok = (x >= 0) & (x < width) & (y >= 0) & (y < height)
+    tiles_x = (width + 15) // 16
+    ids, cnt = np.unique((y[ok] // 16).astype(np.int64) * tiles_x + (x[ok] // 16).astype(np.int64), return_counts=True)
+    return dict(zip(ids.tolist(), cnt.tolist()))
+
+
+def oracle_tile_filter(oracle_scene, tile_ids):
+    """oracle/jade_oracle.c, jade_oracle_set_tile_filter: a checker-only export (the product has no such entry point)."""
+    import ctypes
+    fn = oracle_scene.backend.lib.jade_oracle_set_tile_filter
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]
+    ids = np.ascontiguousarray(tile_ids, np.int32)
+    oracle_scene.backend.check(fn(oracle_scene._h, ids.ctypes.data if len(ids) else None, len(ids)))
+
+
+def tile_mask(width, height, tile_ids):
+    """Boolean [H, W] mask of the pixels of the listed tiles."""
+    tiles_x = (width + 15) // 16
+    m = np.zeros((height, width), bool)
+    for t in tile_ids:
+        ty, tx = divmod(int(t), tiles_x)
+        m[ty * 16:(ty + 1) * 16, tx * 16:(tx + 1) * 16] = True
+    return m

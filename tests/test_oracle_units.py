@@ -192,3 +192,30 @@ def test_reinhard_preview_operator_closed_form(oracle):
     t = c / (1 + (0.3 * c[0] + 0.6 * c[1] + 0.1 * c[2]) / 1.5)
     want = np.floor(np.minimum(255 * t ** (1 / 2.2), 255))[::-1]
     assert np.array_equal(rgb[0, 0], np.float32([3, 2, 1])) and np.abs(bgr[0, 0].astype(int) - want).max() <= 1
+
+
+def test_oracle_tile_filter_renders_exactly_the_listed_tiles(oracle):
+    """jade_oracle_set_tile_filter (checker-only): the listed tiles come out bit-identical to an unfiltered render, the
+    rest is untouched, and the counters are those of the listed tiles alone (a second filter on the complement adds up)."""
+    from conftest import config_scene, counters, oracle_tile_filter, tile_mask
+    hs, cfg = config_scene("tinyjade")
+    p = B.params_from_config(cfg, spp=3)
+    p.width, p.height = 70, 50
+    tiles_x = 5
+    keep = [0, 3, 7, 4 * tiles_x - 1]
+    rest = [t for t in range(tiles_x * 4) if t not in keep]
+    with oracle.scene(hs) as so:
+        full, full_b, st_full = so.render(p)
+        oracle_tile_filter(so, keep)
+        a, a_b, st_a = so.render(p)
+        oracle_tile_filter(so, rest)
+        b, b_b, st_b = so.render(p)
+        oracle_tile_filter(so, [])
+        c, c_b, st_c = so.render(p)
+    m = tile_mask(70, 50, keep)
+    assert np.array_equal(a[m].view(np.uint32), full[m].view(np.uint32)) and not a[~m].any()
+    assert np.array_equal(b[~m].view(np.uint32), full[~m].view(np.uint32)) and not b[m].any()
+    assert np.array_equal((a + b).view(np.uint32), full.view(np.uint32)) and np.array_equal(a_b + b_b, full_b)
+    tot = {k: counters(st_a)[k] + counters(st_b)[k] for k in counters(st_a)}
+    assert tot == counters(st_full) == counters(st_c)
+    assert np.array_equal(c.view(np.uint32), full.view(np.uint32))
