@@ -18,20 +18,24 @@ the K steps — `samples` = K * spp * pixels, and all their rays — is computed
 
 value = (primary + secondary rays traced by all ranks in the K timed steps) / max-over-ranks wall time, Mray/s.
         A ray = one hitBVH query (PathTrace.cu:795).
-roofline: the dominant kernel, k_trace (BVH traversal + triangle tests), against the arithmetic roof of a kernel
-        without matrix work: VALU issue.  achieved = VALU lane-operations per second = (lane-ops per ray,
-        SQ_THREAD_CYCLES_VALU from the rocprofv3 --pmc pass of this same command, profiles/valu_issue.json) x (rays
-        this run traced) / (k_trace time of this run, HIP events on the kernel's own stream); peak = 1024 SIMDs x 32
-        lanes per clock x 2.4 GHz (see VALU_PEAK_TLANEOPS).  frac = (lanes active per VALU instruction / 64) x (VALU
-        instructions issued per SIMD per 2 clocks) x (clock held / 2.4 GHz), <= 1.  `binding` says what limits the
-        kernel on this configuration: on C3 (scene L2-resident) NO unit is saturated since the wave-wide leaf queue cut
-        the instructions per ray by a third - the kernel is bound by the latency of a ray's chain of dependent node
-        visits (`sensitivity` carries the ablations, profiles/sensitivity_r02.json); on C5 (873k
-        triangles: 51 % L2 hits, 5.9 TB/s) it is HBM.
-roofline_hbm: the HBM view SURVEY.md 8d prices the path with.  achieved = MEASURED HBM bytes (PMC FETCH_SIZE x 2 +
-        WRITE_SIZE per ray, profiles/hbm_traffic.json) x rays / k_trace time, against 8 TB/s; `algorithmic_GBps` is
-        the reference traversal's 40 B per node record + 36 B per triangle test delivered per second — it exceeds
-        the HBM peak because the scene is L2-resident, which is why it is not a roofline.
+rooflines: the dominant kernel, k_trace (BVH traversal + triangle tests), against the three resources a traversal without
+        matrix work can be bound by.  Each: achieved = (per-ray counter figure from the rocprofv3 --pmc passes of this same
+        command, profiles/k_trace_counters.json) x (rays this run traced) / (k_trace time of this run, HIP events on the
+        kernel's own stream).
+          valu  VALU lane-operations (SQ_THREAD_CYCLES_VALU) against 1024 SIMDs x 32 lanes/clock x 2.4 GHz;
+          l2    requests to the XCDs' L2s (TCC_HIT + TCC_MISS) x 64 B against the 16.8 TB/s MI355X_MICROARCH.md measures for
+                gathers served by the L2 (its low end: 16.8-18.8);
+          hbm   fabric-side bytes (FETCH_SIZE x the factor tools/fetch_calib measured for this access pattern + WRITE_SIZE)
+                against 8 TB/s.
+        `roofline` is the one with the largest fraction - the binding resource - and `binding` names it.  The per-ray
+        figures belong to a build: profiles/k_trace_counters.json carries a hash of csrc/ and the fractions are null when
+        the tree's differs (a kernel edit without re-profiling must not keep the old numbers).
+        `algorithmic`: SURVEY.md 8d's 40 B per node record + 36 B per triangle test, per kernel (V and T are counted
+        separately for k_light and k_trace); it exceeds the HBM peak when the scene is cache-resident, which is why it is
+        reported beside the rooflines and not as one.
+parity_check: the frame this run rendered (every sample of warm-up + timed steps) against the oracle on a few of its
+        16x16 tiles - statue, mirror floor, sky - at the full sample count: relative L2 of the radiance, largest BGR8
+        difference.  Outside the timed region; part of the cpu_baseline leg (the oracle is the checker, never the product).
 cpu_baseline: the CPU oracle ("port": the reference has no CPU integrator) on a bounded sample of the same scene,
         rank 0 at N = 1 only.
 extras (N = 1): secondary rays by call site, and the same scene with the camera moved in until the statue fills
@@ -49,6 +53,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s
+L2_GATHER_PEAK_GBS = 16800.0               # MI355X_MICROARCH.md, "Indexed rows": rows served by the XCDs' L2s, 16.8-18.8 TB/s chip-wide
 # VALU issue roof (MI355X_MICROARCH.md: 4 SIMD-32 per CU, a wave64 VALU instruction issues in 2 clocks): 32 lane-operations per
 # clock per SIMD.  That rate needs instructions the sequencer can pair (SQ_ACTIVE_INST_VALU2); a wave's own dependent stream issues
 # one per 4 clocks, which is the unit SQ_ACTIVE_INST_VALU counts in (1.007 quad-cycles per VALU instruction in every kernel
@@ -77,6 +82,9 @@ def parse():
     ap.add_argument("--virtual-ranks", type=int, default=0,
                     help="development: render rank 0's share of a V-GPU run on this one GPU (partition and spp as at N=V)")
     ap.add_argument("--cpu-spp", type=int, default=8, help="oracle sample: spp over the full frame")
+    ap.add_argument("--max-state-gb", type=float, default=0.0, help="jade_render_params.max_state_bytes: device memory for path records + partial sums (0 = the default, 60 %% of what is free)")
+    ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle spot check of the rendered frame")
+    ap.add_argument("--parity-rays", type=float, default=1.2e8, help="oracle rays the parity check may cost (about 7 Mray/s on 16 cores)")
     return ap.parse_args()
 
 
@@ -98,6 +106,18 @@ def profile_json(name):
         return json.load(open(os.path.join(ROOT, "profiles", name)))
     except Exception:
         return None
+
+
+def csrc_hash():
+    """sha256 over the sources the device code is built from (tools/summarize_prof.py stamps the counter files with it)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "jaderaytracerendering_amd", "csrc", "*.h*"))) + [os.path.join(ROOT, "include", n) for n in ("jade_fpmath.h", "jade_rt.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -151,6 +171,11 @@ def main():
                            tile_nranks=part_world, device_id=local_rank)
     if rehearsal and world > 1:  # ranks share one GPU: each may hold its share of the memory, not 60 % of what is free
         params.max_state_bytes = int(0.6 * torch.cuda.mem_get_info(local_rank)[0] / world)
+    if args.max_state_gb > 0:
+        params.max_state_bytes = int(args.max_state_gb * 1e9)
+    # the render is announced with every sample it will get (warm-up + timed steps): the backend sizes its records per
+    # pixel and partial sums from it (jade_rt.h)
+    params.spp = spp_step * (args.warmup + args.steps)
     scene = hip.scene(hs, device_id=local_rank)
 
     def barrier():
@@ -160,6 +185,8 @@ def main():
         torch.cuda.synchronize()
 
     scene.begin(params)
+    state = {"records_per_pixel": scene.query(_abi.Q_RECORDS_PER_PIXEL), "state_bytes": scene.query(_abi.Q_STATE_BYTES),
+             "sum_lanes": scene.query(_abi.Q_SUM_LANES), "max_state_bytes": int(params.max_state_bytes) or None}
     st_w = _abi.Stats()
     for _ in range(args.warmup):
         scene.step(spp_step, st_w)
@@ -204,44 +231,65 @@ def main():
         # rooflines of the dominant kernel (k_trace) on THIS rank
         # k_trace traces what the fused first-pass kernel (k_light: camera rays, floor mirrors) did not trace itself
         rays_rank = float(st.rays_primary + st.rays_secondary - st.rays_inline)
-        alg_bytes = 40.0 * st.nodes_visited + 36.0 * st.tris_tested  # (whole step: V and T are not split by kernel)
+        v_trace, t_trace = float(st.nodes_visited - st.nodes_inline), float(st.tris_tested - st.tris_inline)
+        alg_trace = 40.0 * v_trace + 36.0 * t_trace          # bytes the reference traversal needs for k_trace's rays
+        alg_light = 40.0 * st.nodes_inline + 36.0 * st.tris_inline
         launches = max(int(st.trace_launches), 1)
         trace_s = st.trace_ms * 1e-3
-        # per-ray counter figures exist for the configurations that were profiled (same scene, frame and BVH)
+        # per-ray counter figures exist for the configurations that were profiled (same scene, frame and BVH) - and for one build
         key = {"C3": "C3", "C4": "C3", "C5": "C5"}.get(args.config) if (args.bvh == "sah" and not args.width and not args.height) else None
-        valu = (profile_json("valu_issue.json") or {}).get(key)
-        hbm = (profile_json("hbm_traffic.json") or {}).get(key)
-        roof = {"bound": "valu", "kernel": "k_trace", "achieved": None, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s", "frac": None,
-                "traffic": None, "avg_launch_ms": st.trace_ms / launches, "launches": launches,
-                "trace_share_of_step_time": trace_s / (st.kernel_ms * 1e-3) if st.kernel_ms else None,
-                # what a profiler sees for the same command: every k_trace launch of the process, warm-up included (launches count
-                # the empty ones behind the end of a step's batch too - they are launches, of a few microseconds)
-                "launches_incl_warmup": launches + int(st_w.trace_launches),
-                "avg_launch_ms_incl_warmup": (st.trace_ms + st_w.trace_ms) / max(launches + int(st_w.trace_launches), 1),
-                "rays_per_launch": rays_rank / launches, "rays_traced_by_this_kernel": rays_rank,
-                "Mray_per_s_of_this_kernel": rays_rank / trace_s / 1e6 if trace_s > 0 else None}
-        if valu and valu.get("valu_lane_ops_per_ray") and trace_s > 0:
-            ach = valu["valu_lane_ops_per_ray"] * rays_rank / trace_s / 1e12
-            roof.update({"achieved": ach, "frac": ach / VALU_PEAK_TLANEOPS, "issue_busy_of_2": valu.get("valu_busy"),
-                         "valu_lane_ops_per_ray": valu["valu_lane_ops_per_ray"], "valu_wave_insts_per_ray": valu.get("valu_wave_insts_per_ray"),
-                         "lanes_per_valu_inst_of_64": valu.get("lanes_per_valu_inst"), "valu_busy_profiled": valu.get("valu_busy"),
-                         "counters_from": valu.get("source"),
-                         "note": "lane-ops per ray from the rocprofv3 --pmc SQ pass of this command (tracked summary named in "
-                                 "counters_from); rays and k_trace time are this run's.  frac = share of the chip's VALU lane-slots (32 per "
-                                 "SIMD per clock) that carry this kernel's work; issue_busy_of_2 = 4 x SQ_ACTIVE_INST_VALU / SIMD-cycles"})
-        roof_hbm = {"bound": "hbm", "kernel": "k_trace", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                    "algorithmic_GBps": alg_bytes / (trace_s + st.light_ms * 1e-3) / 1e9 if trace_s > 0 else None,
-                    "algorithmic_bytes_per_launch": alg_bytes / launches,
-                    "algorithmic_bytes_per_ray": alg_bytes / float(st.rays_primary + st.rays_secondary),
-                    "note_algorithmic": "40 B x V + 36 B x T of ALL rays of the step (k_light's included) over k_trace's time alone would overstate: "
-                                        "algorithmic_GBps divides by the device time of both tracing kernels"}
-        if hbm and hbm.get("k_trace_hbm_bytes_per_ray") and trace_s > 0:
-            b = hbm["k_trace_hbm_bytes_per_ray"] * rays_rank
-            roof_hbm.update({"achieved": b / trace_s / 1e9, "frac": b / trace_s / 1e9 / HBM_PEAK_GBS, "traffic": b / launches,
-                             "l2_hit_rate_profiled": hbm.get("k_trace_l2_hit_rate"), "counters_from": hbm.get("source"),
-                             "note": "measured HBM bytes (2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md) per ray from the --pmc passes "
-                                     "of this command; the BVH is cache-resident, so HBM sees the ray records, not the traversal"})
-            roof["traffic"] = b / launches
+        ctr_file = profile_json("k_trace_counters.json") or {}
+        tree_sha = csrc_hash()
+        stale = ctr_file.get("csrc_sha") != tree_sha
+        ctr = None if stale else ctr_file.get(key)
+        common = {"kernel": "k_trace", "avg_launch_ms": st.trace_ms / launches, "launches": launches}
+
+        def roof_of(bound, per_ray, scale, peak, unit, extra=None):
+            r = {"bound": bound, "achieved": None, "peak": peak, "unit": unit, "frac": None, "traffic": None}
+            r.update(common)
+            if per_ray and trace_s > 0:
+                r["achieved"] = per_ray * rays_rank / trace_s / scale
+                r["frac"] = r["achieved"] / peak
+            if extra:
+                r.update(extra)
+            return r
+
+        c = ctr or {}
+        hbm_per_ray = c.get("hbm_bytes_per_ray")
+        rooflines = {
+            "valu": roof_of("valu", c.get("valu_lane_ops_per_ray"), 1e12, VALU_PEAK_TLANEOPS, "Tlane-op/s",
+                            {"valu_wave_insts_per_ray": c.get("valu_wave_insts_per_ray"), "lanes_per_valu_inst_of_64": c.get("lanes_per_valu_inst"),
+                             "issue_busy_of_2": c.get("valu_busy"),
+                             "note": "peak = one wave64 VALU instruction per SIMD per 2 clocks (MI355X_MICROARCH.md: 2 cycles on a SIMD-32, which "
+                                     "takes two or more waves per SIMD; ONE wave's own stream issues one per 4); issue_busy_of_2 = 4 x SQ_ACTIVE_INST_VALU / SIMD-cycles"}),
+            "l2": roof_of("l2", (c.get("l2_requests_per_ray") or 0) * 64.0, 1e9, L2_GATHER_PEAK_GBS, "GB/s",
+                          {"l2_requests_per_ray": c.get("l2_requests_per_ray"), "l2_hit_rate": c.get("l2_hit_rate"),
+                           "note": "(TCC_HIT_sum + TCC_MISS_sum) x 64 B per ray; peak = what the guide measures for gathers served by the XCDs' L2s (16.8-18.8 TB/s)"}),
+            "hbm": roof_of("hbm", hbm_per_ray, 1e9, HBM_PEAK_GBS, "GB/s",
+                           {"fetch_size_factor": c.get("fetch_size_factor"), "note": "FETCH_SIZE x fetch_size_factor + WRITE_SIZE per ray; the factor is what "
+                            "tools/fetch_calib measured for 64-B gathers (profiles/fetch_calibration.json); Infinity-Cache hits are inside FETCH_SIZE"}),
+        }
+        for r in rooflines.values():
+            r["counters_from"] = c.get("source")
+            if r["bound"] == "hbm" and hbm_per_ray:
+                r["traffic"] = hbm_per_ray * rays_rank / launches
+        ranked = [r for r in rooflines.values() if r["frac"] is not None]
+        roof = dict(max(ranked, key=lambda r: r["frac"])) if ranked else dict(rooflines["hbm"])
+        if hbm_per_ray:
+            roof["traffic"] = hbm_per_ray * rays_rank / launches   # measured HBM-side bytes per launch, whatever the bound
+        roof.update({
+            "trace_share_of_step_time": trace_s / (st.kernel_ms * 1e-3) if st.kernel_ms else None,
+            # what a profiler sees for the same command: every k_trace launch of the process, warm-up included (launches count
+            # the empty ones behind the end of a step's batch too - they are launches, of a few microseconds)
+            "launches_incl_warmup": launches + int(st_w.trace_launches),
+            "avg_launch_ms_incl_warmup": (st.trace_ms + st_w.trace_ms) / max(launches + int(st_w.trace_launches), 1),
+            "rays_per_launch": rays_rank / launches, "rays_traced_by_this_kernel": rays_rank,
+            "Mray_per_s_of_this_kernel": rays_rank / trace_s / 1e6 if trace_s > 0 else None,
+            "algorithmic_bytes_per_launch": alg_trace / launches,
+            "algorithmic_GBps": alg_trace / trace_s / 1e9 if trace_s > 0 else None,
+            "counters_build": ctr_file.get("csrc_sha"), "tree_build": tree_sha,
+            "counters_stale": ("profiles/k_trace_counters.json was cut from another build of csrc/ (%s, tree %s): fractions withheld"
+                               % (ctr_file.get("csrc_sha"), tree_sha)) if stale else None})
         out = {
             "metric": "Mray/s (primary+secondary)",
             "value": rays_all / dt / 1e6,
@@ -271,10 +319,18 @@ def main():
             # the step by kernel on this rank: k_light (fused first pass: light samples traced and shaded in one kernel),
             # k_trace (everything else that is traced), the rest = k_shade / k_arm / gaps
             "kernels": {"k_light": {"ms_per_step": st.light_ms / max(args.steps, 1), "rays": float(st.rays_inline),
-                                    "Mray_per_s": st.rays_inline / (st.light_ms * 1e-3) / 1e6 if st.light_ms else None},
+                                    "Mray_per_s": st.rays_inline / (st.light_ms * 1e-3) / 1e6 if st.light_ms else None,
+                                    "nodes_per_ray": st.nodes_inline / max(float(st.rays_inline), 1.0), "tris_per_ray": st.tris_inline / max(float(st.rays_inline), 1.0),
+                                    "algorithmic_bytes_per_ray": alg_light / max(float(st.rays_inline), 1.0),
+                                    "algorithmic_GBps": alg_light / (st.light_ms * 1e-3) / 1e9 if st.light_ms else None},
                         "k_trace": {"ms_per_step": st.trace_ms / max(args.steps, 1), "rays": rays_rank,
-                                    "Mray_per_s": rays_rank / trace_s / 1e6 if trace_s > 0 else None},
-                        "device_ms_per_step": st.kernel_ms / max(args.steps, 1)},
+                                    "Mray_per_s": rays_rank / trace_s / 1e6 if trace_s > 0 else None,
+                                    "nodes_per_ray": v_trace / max(rays_rank, 1.0), "tris_per_ray": t_trace / max(rays_rank, 1.0),
+                                    "algorithmic_bytes_per_ray": alg_trace / max(rays_rank, 1.0),
+                                    "algorithmic_GBps": alg_trace / trace_s / 1e9 if trace_s > 0 else None},
+                        "device_ms_per_step": st.kernel_ms / max(args.steps, 1),
+                        "rest_ms_per_step": (st.kernel_ms - st.trace_ms - st.light_ms) / max(args.steps, 1)},
+            "state": state,
             "rays_by_call_site": {k[5:]: float(vals[6 + i].item()) for i, k in enumerate(cls_keys)},
             "gather_ms": gather_ms,
             "frame_ok": frame_ok,
@@ -286,20 +342,19 @@ def main():
             "bvh": args.bvh, "device_bvh_ms": dev_build_ms,
             "nodes_per_ray": float(vals[1].item()) / rays_all, "tris_per_ray": float(vals[2].item()) / rays_all,
             "roofline": roof,
-            "roofline_hbm": roof_hbm,
-            # HBM when the measured traffic is the larger share of its roof; otherwise neither roof binds
-            "binding": None if roof["frac"] is None or roof_hbm["frac"] is None else
-                       ("hbm" if roof_hbm["frac"] > roof["frac"] else "latency (no unit saturated: VALU issue %.2f of 2, HBM %.0f %% of peak)"
-                        % (roof.get("issue_busy_of_2") or 0.0, 100.0 * roof_hbm["frac"])),
+            "rooflines": rooflines,
+            # the resource with the largest share of its roof (null when the counter file belongs to another build)
+            "binding": roof["bound"] if roof.get("frac") is not None else None,
         }
-        sens = profile_json("sensitivity_r02.json")
-        if sens and key == "C3":
-            out["sensitivity"] = {"source": "profiles/sensitivity_r02.json", "k_trace_ms_per_256spp_step": sens.get("ablations_k_trace_ms_per_256spp_step"),
-                                  "reading": sens.get("reading")}
+        parity_frame = None
+        if world == 1 and part_world == 1 and not args.no_cpu_baseline and not args.no_parity_check:
+            parity_frame = scene.resolve()   # (rgb, bgr8) of the frame the timed region finished: host copies, outside the clock
         if world == 1 and part_world == 1 and not args.no_extras and args.config in ("C2", "C3", "C4"):
             out["statue_closeup"] = closeup(scene, hip, B, H, _abi, cfg, width, height, args.spp_per_step)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(hs, cfg, width, height, args.cpu_spp)
+            if parity_frame is not None:
+                out["parity_check"] = parity_check(hs, cfg, width, height, int(params.spp), parity_frame, args.parity_rays)
         print(json.dumps(out), flush=True)
     scene.close()
     if world > 1:
@@ -332,6 +387,60 @@ def closeup(scene, hip, B, H, _abi, cfg, width, height, spp):
             "k_trace_Mray_per_s": rays / (st.trace_ms * 1e-3) / 1e6 if st.trace_ms else None,
             "trace_share_of_step_time": st.trace_ms / st.kernel_ms if st.kernel_ms else None,
             "camera": "C3's view direction, eye moved to 0.22 from the statue's centre (C3: 0.56)"}
+
+
+def parity_check(hs, cfg, width, height, spp_total, frame, ray_budget):
+    """The rendered frame against the oracle on a few tiles at the full sample count (the checker leg: the oracle is
+    test infrastructure and is only ever compared WITH).  Tiles: the statue tile with the most vertices, a tile of the
+    mirror floor, a sky tile, then more statue / edge tiles while the oracle's estimated rays fit the budget."""
+    import ctypes
+    import numpy as np
+    from jaderaytracerendering_amd import backend as B, host as H
+    lib = os.path.join(ROOT, "oracle", "libjade_oracle.so")
+    if not os.path.exists(lib):
+        return None
+    rgb, bgr = frame
+    tiles_x, tiles_y = (width + 15) // 16, (height + 15) // 16
+    statue = H.object_tiles(hs, cfg.eye, cfg.camera, width, height, obj=0)
+    by_count = sorted(statue, key=statue.get, reverse=True)
+    cand = []   # (tile id, estimated rays per sample)
+    if by_count:
+        cand.append((by_count[0], 25.0))
+        sty, stx = divmod(by_count[0], tiles_x)
+        cand.append((max(sty - 14, 0) * tiles_x + stx, 2.5))                                  # the mirror floor in front of the statue
+    cand.append(((tiles_y - 3) * tiles_x + 5, 1.0))                                          # sky
+    if len(by_count) > 8:
+        cand.append((by_count[len(by_count) // 2], 15.0))                                     # a tile the statue half covers
+        cand.append((by_count[1], 25.0))
+    cand.append(((tiles_y - 1) * tiles_x + tiles_x - 1, 1.0))                                # the top right corner (a partial tile at 1080p)
+    chosen, cost = [], 0.0
+    for tid, rps in cand:
+        c = 256.0 * spp_total * rps
+        if tid in chosen or (len(chosen) >= 3 and cost + c > ray_budget):
+            continue
+        chosen.append(tid)
+        cost += c
+    oracle = B.Backend(lib)
+    fn = oracle.lib.jade_oracle_set_tile_filter   # checker-only export of oracle/jade_oracle.c
+    fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]
+    ids = np.ascontiguousarray(chosen, np.int32)
+    p = B.make_params(width, height, spp_total, list(cfg.eye), list(cfg.camera), threads=usable_cores())
+    t0 = time.perf_counter()
+    with oracle.scene(hs) as so:
+        oracle.check(fn(so._h, ids.ctypes.data, len(ids)))
+        o_rgb, o_bgr, st = so.render(p)
+    dt = time.perf_counter() - t0
+    m = np.zeros((height, width), bool)
+    for t in chosen:
+        ty, tx = divmod(int(t), tiles_x)
+        m[ty * 16:(ty + 1) * 16, tx * 16:(tx + 1) * 16] = True
+    a, b = rgb[m].astype(np.float64), o_rgb[m].astype(np.float64)
+    rel = float(np.sqrt(((a - b) ** 2).sum()) / max(np.sqrt((b ** 2).sum()), 1e-300))
+    bgr_max = int(np.abs(bgr[m].astype(np.int16) - o_bgr[m].astype(np.int16)).max())
+    return {"tiles": [[int(t % tiles_x), int(t // tiles_x)] for t in chosen], "pixels": int(m.sum()), "spp": spp_total,
+            "rel_l2": rel, "bgr_max": bgr_max, "ok": bool(rel <= 1e-4 and bgr_max <= 1), "tolerance": {"rel_l2": 1e-4, "bgr": 1},
+            "oracle_rays": int(st.rays), "oracle_s": dt,
+            "what": "the frame of this run (warm-up + timed steps, the benchmarked schedule) vs the CPU oracle on these 16x16 tiles at the same sample count"}
 
 
 def usable_cores():

@@ -174,6 +174,9 @@ typedef struct jade_stats {
    * trace_ms / trace_launches cover the other rays only.  Oracle: 0. */
   uint64_t rays_inline;
   double light_ms;         /* HIP: device time of k_light (HIP events), summed over launches; oracle: 0 */
+  /* HIP: the node records / triangle tests (of nodes_visited / tris_tested) that belong to the rays_inline rays, so that
+   * SURVEY 8(d)'s algorithmic bytes 40 V + 36 T can be stated per kernel: k_trace's are the difference.  Oracle: 0. */
+  uint64_t nodes_inline, tris_inline;
 } jade_stats;
 
 typedef struct jade_scene jade_scene; /* opaque */

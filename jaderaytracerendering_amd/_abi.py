@@ -73,6 +73,7 @@ class Stats(C.Structure):
         ("rays_shadow", C.c_uint64), ("rays_env", C.c_uint64), ("rays_indirect", C.c_uint64),
         ("rays_mirror", C.c_uint64), ("rays_refract", C.c_uint64), ("host_syncs", C.c_uint64),
         ("rays_inline", C.c_uint64), ("light_ms", C.c_double),
+        ("nodes_inline", C.c_uint64), ("tris_inline", C.c_uint64),
     ]
 
     def as_dict(self):

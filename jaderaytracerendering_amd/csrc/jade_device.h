@@ -162,7 +162,8 @@ struct DevCounters {  // two 64-B lines per shard; shade_tail adds by word index
   unsigned long long pad[2];  // k_trace development profile (JADE_TRACE_PROFILE)
   unsigned long long rays_env, rays_indirect, rays_mirror, rays_refract;  // with rays_shadow: rays_secondary by call site (jade_rt.h)
   unsigned long long rays_inline;  // rays k_light traced itself (primary + mirror)
-  unsigned long long pad2[3];
+  unsigned long long nodes_inline, tris_inline;  // ... and their share of nodes_visited / tris_tested
+  unsigned long long pad2[1];
 };
 #ifndef JADE_TRACE_CHUNK
 #define JADE_TRACE_CHUNK 512 /* most rays a wave claims per queue atomic */

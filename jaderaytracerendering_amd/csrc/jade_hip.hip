@@ -933,6 +933,8 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_LIGHT_WAVES) void k_light(De
       DevCounters* cs = ctr + (blockIdx.x % JADE_CTR_SHARDS);
       if (sv) atomicAdd(&cs->nodes_visited, sv);
       if (stt) atomicAdd(&cs->tris_tested, stt);
+      if (sv) atomicAdd(&cs->nodes_inline, sv);
+      if (stt) atomicAdd(&cs->tris_inline, stt);
       if (s0 + s6) atomicAdd(&cs->rays_inline, (unsigned long long)s0 + s6);  // every camera and mirror ray of this kernel was traced here
     }
     __syncthreads();
@@ -1658,6 +1660,7 @@ static hipError_t sum_counters(jade_scene* s, DevCounters* out) {
     out->rays_env += c.rays_env; out->rays_indirect += c.rays_indirect;
     out->rays_mirror += c.rays_mirror; out->rays_refract += c.rays_refract;
     out->rays_inline += c.rays_inline;
+    out->nodes_inline += c.nodes_inline; out->tris_inline += c.tris_inline;
     out->pad[0] += c.pad[0]; out->pad[1] += c.pad[1];
   }
   return e;
@@ -1985,6 +1988,8 @@ static int advance(jade_scene* s, int64_t from0, bool may_carry, jade_stats* st)
     st->rays_mirror += c.rays_mirror;
     st->rays_refract += c.rays_refract;
     st->rays_inline += c.rays_inline;
+    st->nodes_inline += c.nodes_inline;
+    st->tris_inline += c.tris_inline;
     st->light_ms += s->light_ms;
     st->nodes_visited += c.nodes_visited;
     st->tris_tested += c.tris_tested;
@@ -2248,6 +2253,7 @@ int jade_render_multi(jade_scene* const* scenes, int ndev, const jade_render_par
       st->rays_shadow += sts[i].rays_shadow; st->rays_env += sts[i].rays_env; st->rays_indirect += sts[i].rays_indirect;
       st->rays_mirror += sts[i].rays_mirror; st->rays_refract += sts[i].rays_refract; st->host_syncs += sts[i].host_syncs;
       st->rays_inline += sts[i].rays_inline;
+      st->nodes_inline += sts[i].nodes_inline; st->tris_inline += sts[i].tris_inline;
       st->light_ms = std::max(st->light_ms, sts[i].light_ms);
       st->nodes_visited += sts[i].nodes_visited; st->tris_tested += sts[i].tris_tested;
       st->shaded_hits += sts[i].shaded_hits; st->samples += sts[i].samples;

@@ -283,6 +283,23 @@ def build_config(name):
         b.close()
 
 
+def object_tiles(hs, eye, camera, width, height, obj=0):
+    """{tile id (ty * tiles_x + tx): vertices of object `obj` that project into it}: the camera mapping of
+    PathTrace.cu:1430-1437 inverted (dir ~ M . (lx * W/H, ly, -1.5, 0), lx = -1 + 2/W (x + u - 0.5), M[col][row])."""
+    v = hs.vertices()[hs.tri_i32()[:, 0] == obj].reshape(-1, 3).astype(np.float64)
+    m = np.asarray(list(camera), np.float64).reshape(4, 4)
+    rel = v - np.asarray(list(eye), np.float64)
+    a, b, c = rel @ m[0, :3], rel @ m[1, :3], rel @ m[2, :3]
+    front = c < 0
+    s = -1.5 / c[front]
+    lx, ly = a[front] * s / (width / height), b[front] * s
+    x, y = np.floor((lx + 1) * width / 2), np.floor((ly + 1) * height / 2)
+    ok = (x >= 0) & (x < width) & (y >= 0) & (y < height)
+    tiles_x = (width + 15) // 16
+    ids, cnt = np.unique((y[ok] // 16).astype(np.int64) * tiles_x + (x[ok] // 16).astype(np.int64), return_counts=True)
+    return dict(zip(ids.tolist(), cnt.tolist()))
+
+
 def write_bmp(path, bgr8):
     h, w = bgr8.shape[:2]
     a = np.ascontiguousarray(bgr8, np.uint8)

@@ -99,20 +99,9 @@ def fpm():
 
 
 def object_tiles(hs, cfg, width, height, obj=0):
-    """Tile ids (ty * tiles_x + tx) the vertices of object `obj` project into, with the number of vertices per tile: the
-    camera mapping of PathTrace.cu:1430-1437 inverted (dir ~ M . (lx * W/H, ly, -1.5, 0), lx = -1 + 2/W (x + u - 0.5))."""
-    v = hs.vertices()[hs.tri_i32()[:, 0] == obj].reshape(-1, 3).astype(np.float64)
-    m = np.asarray(list(cfg.camera), np.float64).reshape(4, 4)  # [col][row]
-    rel = v - np.asarray(list(cfg.eye), np.float64)
-    a, b, c = rel @ m[0, :3], rel @ m[1, :3], rel @ m[2, :3]
-    front = c < 0
-    s = -1.5 / c[front]
-    lx, ly = a[front] * s / (width / height), b[front] * s
-    x, y = np.floor((lx + 1) * width / 2), np.floor((ly + 1) * height / 2)
-    ok = (x >= 0) & (x < width) & (y >= 0) & (y < height)
-    tiles_x = (width + 15) // 16
-    ids, cnt = np.unique((y[ok] // 16).astype(np.int64) * tiles_x + (x[ok] // 16).astype(np.int64), return_counts=True)
-    return dict(zip(ids.tolist(), cnt.tolist()))
+    """Tile ids the vertices of object `obj` project into (host.object_tiles)."""
+    from jaderaytracerendering_amd import host as H
+    return H.object_tiles(hs, cfg.eye, cfg.camera, width, height, obj)
 
 
 def oracle_tile_filter(oracle_scene, tile_ids):

@@ -2,9 +2,10 @@
 # GPU box, development: where does k_trace's time go?  (1) occupancy sweep, (2) SQ / TA / TCP counter groups on a short run.
 # usage: tools/diag_r02.sh <tag> [bench args...]
 R=${GRAFT_REPO_ROOT:-/root/repo}
+[ -n "$1" ] || { echo "usage: $0 <tag> [bench args...]"; exit 2; }
 tag=$1; shift
-O=$R/gpurun_out/$tag
-rm -rf $O; mkdir -p $O
+O="$R/gpurun_out/$tag"
+rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 1 --warmup 1 --spp-per-step 256 --no-cpu-baseline --no-extras $@"
 for k in 2 3 4 5 6; do

@@ -3,6 +3,7 @@
 # usage: tools/pmc_passes.sh <tag> <spp-per-step> "<group1 counters>" "<group2 counters>" ...
 set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}
+[ -n "$2" ] || { echo "usage: $0 <tag> <spp-per-step> \"<counters>\" ..."; exit 2; }
 tag=$1; spp=$2; shift 2
 cd /tmp && export TMPDIR=/tmp
 i=0

@@ -3,6 +3,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/pmcq; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
+[ -n "$1" ] || { echo "usage: $0 \"<counters>\" [bench args]"; exit 2; }
 grp=$1; shift
 timeout -k 10 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/p -- python3 $R/bench.py --steps 1 --warmup 1 --spp-per-step 256 --no-cpu-baseline --no-extras "$@" > $O/p.log 2>&1
 python3 - <<PY

@@ -10,9 +10,10 @@
 set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}
 tag=$1
-O=$R/gpurun_out/$tag
-rm -rf $O
-mkdir -p $O
+[ -n "$tag" ] || { echo "usage: $0 <tag> [C5]"; exit 2; }
+O="$R/gpurun_out/$tag"
+rm -rf "$O"
+mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 SQ="SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU"
 timeout -k 10 600 python3 $R/bench.py > $O/bench.json 2> $O/bench.err

@@ -5,9 +5,10 @@
 set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}
 tag=$1
-O=$R/gpurun_out/$tag
-rm -rf $O
-mkdir -p $O
+[ -n "$tag" ] || { echo "usage: $0 <tag>"; exit 2; }
+O="$R/gpurun_out/$tag"
+rm -rf "$O"
+mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 900 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 tail -c 600 $O/bench.json; echo

@@ -1,8 +1,9 @@
 #!/bin/bash
 # GPU box, development: the SQ issue counters of one short bench run per library variant.  usage: tools/sq_quick.sh <tag> [variant suffixes...]
 R=${GRAFT_REPO_ROOT:-/root/repo}
+[ -n "$1" ] || { echo "usage: $0 <tag> [variant suffixes...]"; exit 2; }
 tag=$1; shift
-O=$R/gpurun_out/$tag; rm -rf $O; mkdir -p $O
+O="$R/gpurun_out/$tag"; rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 SQ="SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_SALU"
 for v in "$@"; do
