@@ -51,6 +51,12 @@ variant: $(HIP_SRC) $(HIP_HDR)
 $(LIBDIR)/jade_render: $(PKG)/host/jade_render_cli.cpp $(LIBDIR)/libjade_host.so $(HOST_HDR)
 	$(CXX) $(CXXFLAGS) -o $@ $(PKG)/host/jade_render_cli.cpp -L$(LIBDIR) -ljade_host -ldl -Wl,-rpath,'$$ORIGIN'
 
+# FETCH_SIZE / TCC_* calibration on k_trace's access pattern (tools/calib/fetch_calib.hip; run under rocprofv3 --pmc)
+calib: $(LIBDIR)/fetch_calib
+$(LIBDIR)/fetch_calib: $(ROOT)/tools/calib/fetch_calib.hip
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) -O3 -std=c++17 --offload-arch=gfx950 -o $@ $<
+
 # AddressSanitizer + UBSan over the CPU side (host pipeline, CLI, oracle).  GPU ASan is not
 # available on the pool, so this is where memory errors of the non-device code are hunted.
 SAN := -fsanitize=address,undefined -fno-omit-frame-pointer -O1 -g
@@ -68,4 +74,4 @@ clean:
 	rm -rf $(LIBDIR)
 	$(MAKE) -C $(ROOT)/oracle clean
 
-.PHONY: all host hip hipvariants variant oracle cli clean asan-check
+.PHONY: all host hip hipvariants variant oracle cli clean asan-check calib

@@ -33,8 +33,6 @@
 #include <string>
 #include <vector>
 
-#include <rocprim/device/device_radix_sort.hpp>
-
 #include "jade_device.h"
 #include "jade_shade.h"
 #include "jade_trace.h"
@@ -486,35 +484,6 @@ __global__ __launch_bounds__(JADE_LEAN_BLOCK) void k_shade_lean(DevScene S, Path
   shade_tail<true, JADE_LEAN_BLOCK / 64>(P, p, st, c, defer, nullptr, heavy_out, queue, qc, ctr);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Ray-queue ordering (north_star: "ray compaction/sort via wave-ballot/prefix-sum primitives").  k_trace's cost is the
-// number of distinct cache lines a wave's 64 rays pull through the L1 / L2 path per unit of work; which ray sits beside
-// which in the queue is free to choose (every result is written back to the ray's own slot, so no bit of any result
-// depends on the order).  A ray's key: the kind of ray (shadow ray towards emitter i / environment ray / indirect ray /
-// single-ray stage), then where it starts - the triangle it leaves, whose index in BVH order is a place on the tree's own
-// space-filling curve - and the octant it heads into.
-// ---------------------------------------------------------------------------------------------------------------
-__global__ void k_ray_keys(PathState P, const uint32_t* queue, uint32_t n, uint32_t* keys, int n_emit, uint32_t tri_shift, uint32_t oct_mode,
-                           uint32_t tri_bits) {  // tri_bits: bits of the largest (triangle index >> tri_shift); the key is left-aligned
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t e = queue[i];
-  const uint32_t p = e / (uint32_t)P.nslots, k = e - p * (uint32_t)P.nslots;
-  const uint32_t st = P.hdr[p].z & 255u;
-  const float4 og = P.orgs[p];
-  const int32_t skip = __float_as_int(og.w);
-  const float4 dv = P.slot[(size_t)e * 2];
-  uint32_t cls = 7u;  // single-ray stages (mirror, refraction, camera)
-  if (st == ST_DIFFUSE || st == ST_BSSRDF) cls = (int)k < n_emit ? (k < 5u ? k : 4u) : ((int)k == n_emit ? 5u : 6u);
-  const uint32_t tri = skip < 0 ? 0u : ((uint32_t)skip >> tri_shift);
-  const uint32_t oct = (dv.x < 0.0f ? 1u : 0u) | (dv.y < 0.0f ? 2u : 0u) | (dv.z < 0.0f ? 4u : 0u);
-  uint32_t key;
-  if (oct_mode == 2u) key = (cls << 29) | (oct << 26) | (tri << (26u - tri_bits));
-  else if (oct_mode == 1u) key = (cls << 29) | (((tri << 3) | oct) << (26u - tri_bits));
-  else key = (cls << 29) | (tri << (29u - tri_bits));
-  keys[i] = key;
-}
-
 #define JADE_CTL_RING 32 /* QueueCtl records: entry 0 for passes the host follows one by one, all of them for a batch of passes */
 #ifndef JADE_TRACE_NT
 #define JADE_TRACE_NT 1 /* k_trace reads and writes the ray records with non-temporal hints */
@@ -586,11 +555,16 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
   r.sp = stk.col;
   r.pushed = 0;
   r.inv = jv(0, 0, 0);
+#if JADE_PREFETCH
+  r.pre.a = r.pre.b = r.pre.c = make_float4(0, 0, 0, 0);
+  r.pre.rf = make_uint2(0u, 0u);
+#endif
   WaveTrace wt;  // the wave's rings of leaves to test and of hit candidates, and the item this lane is testing (jade_trace.h)
   wt.init(lds_addr_of(&lds_wq[threadIdx.x >> 6][0]), lds_addr_of(&lds_hq[threadIdx.x >> 6][0]), lane);
   TraceProf pr;
 #if JADE_TRACE_PROFILE
-  pr.begin();
+  __shared__ __attribute__((aligned(8))) unsigned long long lds_prof[JADE_TRACE_BLOCK / 64][PL_N];
+  pr.begin(lds_addr_of(reinterpret_cast<const uint32_t*>(&lds_prof[threadIdx.x >> 6][0])), lane);
 #endif
   for (;;) {
     // ---- a ray has ended when its walk has and all the leaves it pushed have been finished
@@ -658,10 +632,11 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
     wt.iterate(r, active, S, stk, vcnt, tcnt, pr);
   }
 #if JADE_TRACE_PROFILE
-  if (lane == 0) {
-    pr.count(PC_WAVES, 1);
-    for (int i = 0; i < PL_N; ++i)
-      if (pr.v[i]) atomicAdd(&g_trace_prof[i], pr.v[i]);
+  pr.count(PC_WAVES, 1);
+  PROF_DRAIN();
+  if (lane < PL_N) {
+    const unsigned long long v = pr.get(lane);
+    if (v) atomicAdd(&g_trace_prof[lane], v);
   }
 #endif
   V += (uint32_t)wave_sum_u32(vcnt);  // (valid in lane 0, the only lane that uses it)
@@ -1085,11 +1060,6 @@ struct Tunables {
   int records_per_pixel = 0;  // JADE_RECORDS_PER_PIXEL: test hook, results must not depend on it
   int trace_blocks_per_cu = 0;  // JADE_TRACE_BLOCKS_PER_CU: occupancy sweeps
   bool force_rccl = false;    // JADE_FORCE_RCCL=1 (tests): the RCCL path for a single share too
-  int sort_mode = 0;          // JADE_SORT: ray-queue ordering before k_trace: 0 none, 1 by (kind, triangle), 2 (kind, octant, triangle), 3 (kind, triangle, octant)
-  int sort_tri_shift = 0;     // JADE_SORT_TRISHIFT: low bits of the triangle index left out of the key
-  int sort_bits = 32;         // JADE_SORT_BITS: key bits sorted on, from the top
-  uint32_t sort_min = 4096;   // JADE_SORT_MIN: queues shorter than this are traced as they are
-  bool log_sort = false;      // JADE_LOG_SORT
   void read() {
     auto flag0 = [](const char* n) { const char* e = getenv(n); return e && atoi(e) == 0; };
     auto flag1 = [](const char* n) { const char* e = getenv(n); return e && atoi(e) > 0; };
@@ -1103,11 +1073,6 @@ struct Tunables {
     if (const char* e = getenv("JADE_RECORDS_PER_PIXEL")) records_per_pixel = atoi(e);
     if (const char* e = getenv("JADE_TRACE_BLOCKS_PER_CU")) trace_blocks_per_cu = atoi(e);
     force_rccl = getenv("JADE_FORCE_RCCL") != nullptr;
-    if (const char* e = getenv("JADE_SORT")) sort_mode = atoi(e);
-    if (const char* e = getenv("JADE_SORT_TRISHIFT")) sort_tri_shift = atoi(e);
-    if (const char* e = getenv("JADE_SORT_BITS")) sort_bits = atoi(e);
-    if (const char* e = getenv("JADE_SORT_MIN")) sort_min = (uint32_t)atoi(e);
-    log_sort = getenv("JADE_LOG_SORT") != nullptr;
   }
 };
 
@@ -1124,7 +1089,6 @@ struct jade_scene {
   jade_render_params rp{};
   RenderConst rc{};
   PathState ps{};
-  DevBuf b_sortkey, b_sorttmp;  // ray-queue ordering (k_sort_*): keys beside the queue, histogram / sorted queue
   DevBuf b_state, b_sum, b_tiles, b_queue, b_active[2], b_ctl, b_ctr, b_spill, b_out_rgb, b_out_bgr, b_wavecnt;
   std::vector<int32_t> tile_ids;
   int trace_blocks = 0;
@@ -1133,21 +1097,12 @@ struct jade_scene {
   bool tail_pending = false;  // the last step left its longest paths unfinished (jade_render_flush)
   hipEvent_t ev[7] = {};      // run_passes' timing events, made once (ev0, ev1, ta, tb, sa, sb, sm)
   hipEvent_t ev_resolve = nullptr;  // jade_render_resolve_tiles_device: caller's stream -> scene stream
-  size_t sort_cap = 0, sort_tmp_bytes = 0;  // ray-queue ordering: rays the buffers hold, rocPRIM's temporary storage
-  DevBuf b_sortkey2, b_sortq;
-  double sort_ms = 0;
-  uint64_t sort_launches = 0;
-  hipEvent_t ev_sort[2] = {};
   uint64_t host_syncs = 0;    // host waits inside step/flush since the last advance() reported them
   double light_ms = 0;        // k_light device time since then
   hipEvent_t ev_light[2] = {};
   hipEvent_t ev_batch[2 * JADE_CTL_RING] = {};  // k_trace timing of a batch of passes
   ~jade_scene() {
     if (ev_resolve) (void)hipEventDestroy(ev_resolve);
-    if (sort_launches && tun.log_sort)
-      fprintf(stderr, "[jade] ray-queue ordering: %.2f ms in %llu sorts\n", sort_ms, (unsigned long long)sort_launches);
-    for (hipEvent_t e : ev_sort)
-      if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_light)
       if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_batch)
@@ -1546,18 +1501,6 @@ static int setup_state(jade_scene* s, int npx, int rpp, int nslots, int sum_lane
   HIP_TRY(s->b_active[0].alloc((N + (size_t)s->light_blocks * JADE_TRACE_BLOCK + 64) * 4));
   HIP_TRY(s->b_active[1].alloc(N * 4));
   HIP_TRY(s->b_wavecnt.alloc((size_t)2 * s->light_blocks * (JADE_TRACE_BLOCK / 64) * 4));
-  s->sort_cap = 0;
-  if (s->tun.sort_mode > 0) {  // (experiment: host-followed passes only)
-    const size_t cap = std::min<size_t>(K * N, (size_t)1 << 28);
-    size_t tmp = 0;
-    HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, cap, 0u, 32u, s->stream));
-    HIP_TRY(s->b_sortkey.alloc(cap * 4));
-    HIP_TRY(s->b_sortkey2.alloc(cap * 4));
-    HIP_TRY(s->b_sortq.alloc(cap * 4));
-    HIP_TRY(s->b_sorttmp.alloc(tmp));
-    s->sort_tmp_bytes = tmp;
-    s->sort_cap = cap;
-  }
   if (!s->b_spill.p)
     HIP_TRY(s->b_spill.alloc((size_t)(JADE_BVH_STACK_CAPACITY - JADE_LDS_STACK) * s->trace_blocks * JADE_TRACE_BLOCK * 4));
   return JADE_OK;
@@ -1883,33 +1826,9 @@ static int run_passes(jade_scene* s, int64_t from_spp, uint32_t target_spp, bool
     }
     n_active = host_ctl[1];
     if (host_ctl[0] == 0) break;
-    const uint32_t* trace_queue = s->b_queue.as<uint32_t>();
-    if (s->tun.sort_mode > 0 && host_ctl[0] >= s->tun.sort_min && host_ctl[0] <= s->sort_cap) {
-      const uint32_t n = host_ctl[0];
-      uint32_t tri_bits = 1;
-      while (tri_bits < 26 && ((uint32_t)(s->dev.n_tris - 1) >> s->tun.sort_tri_shift) >> tri_bits) ++tri_bits;
-      for (hipEvent_t& e : s->ev_sort)
-        if (!e) HIP_TRY(hipEventCreate(&e));
-      HIP_TRY(hipEventRecord(s->ev_sort[0], s->stream));
-      hipLaunchKernelGGL(k_ray_keys, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->ps, s->b_queue.as<uint32_t>(), n, s->b_sortkey.as<uint32_t>(),
-                         s->n_emit, (uint32_t)s->tun.sort_tri_shift, s->tun.sort_mode == 2 ? 2u : s->tun.sort_mode == 3 ? 1u : 0u, tri_bits);
-      size_t tmp = s->sort_tmp_bytes;
-      const unsigned lo = (unsigned)std::max(0, 32 - s->tun.sort_bits);
-      HIP_TRY(rocprim::radix_sort_pairs(s->b_sorttmp.p, tmp, s->b_sortkey.as<uint32_t>(), s->b_sortkey2.as<uint32_t>(), s->b_queue.as<uint32_t>(),
-                                        s->b_sortq.as<uint32_t>(), (size_t)n, lo, 32u, s->stream));
-      HIP_TRY(hipEventRecord(s->ev_sort[1], s->stream));
-      trace_queue = s->b_sortq.as<uint32_t>();
-      if (s->tun.log_sort) {
-        HIP_TRY(hipEventSynchronize(s->ev_sort[1]));
-        float t = 0;
-        HIP_TRY(hipEventElapsedTime(&t, s->ev_sort[0], s->ev_sort[1]));
-        s->sort_ms += t;
-        s->sort_launches += 1;
-      }
-    }
     HIP_TRY(hipEventRecord(ta, s->stream));
     hipLaunchKernelGGL(k_trace, dim3((unsigned)s->trace_blocks), dim3(JADE_TRACE_BLOCK), 0, s->stream, s->dev, s->ps,
-                       trace_queue, qc, s->b_spill.as<uint32_t>(), s->b_ctr.as<DevCounters>(),
+                       s->b_queue.as<uint32_t>(), qc, s->b_spill.as<uint32_t>(), s->b_ctr.as<DevCounters>(),
                        trace_chunk(s, host_ctl[0]));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(tb, s->stream));
@@ -2032,7 +1951,7 @@ int jade_render_query(jade_scene* s, int what, int64_t* value) {
     case JADE_Q_RECORDS_PER_PIXEL: *value = s->ps.npix ? s->ps.rpp : 0; return JADE_OK;
     case JADE_Q_STATE_BYTES:
       *value = s->ps.npix ? (int64_t)(s->b_state.bytes + s->b_sum.bytes + s->b_queue.bytes + s->b_active[0].bytes + s->b_active[1].bytes +
-                                      s->b_wavecnt.bytes + s->b_spill.bytes + s->b_sortkey.bytes + s->b_sorttmp.bytes)
+                                      s->b_wavecnt.bytes + s->b_spill.bytes)
                           : 0;
       return JADE_OK;
     case JADE_Q_SUM_LANES: *value = s->ps.npix ? s->ps.sum_lanes : 0; return JADE_OK;

@@ -68,19 +68,30 @@ enum {
   PL_N
 };
 #if JADE_TRACE_PROFILE
+typedef __attribute__((address_space(3))) unsigned long long jade_prof_lds_u64;
+// The laps live in LDS (one row of PL_N 64-bit words per wave, added to by lane 0): as per-lane variables they were 40
+// more registers and pushed the kernel into scratch, whose traffic then sat inside every lap (first version, round 3).
+// `last` stays a scalar: laps are only taken where the wave's control flow is uniform.
 struct TraceProf {
   unsigned long long last;
-  unsigned long long v[PL_N];
-  __device__ __forceinline__ void begin() {
-    for (int i = 0; i < PL_N; ++i) v[i] = 0;
+  uint32_t row;  // LDS byte address of this wave's row
+  bool lead;     // lane 0
+  __device__ __forceinline__ void begin(uint32_t row_addr, int lane) {
+    row = row_addr;
+    lead = lane == 0;
+    if (lane < PL_N) *(jade_prof_lds_u64*)(__SIZE_TYPE__)(row + 8u * (uint32_t)lane) = 0ull;
     last = __builtin_amdgcn_s_memtime();
+  }
+  __device__ __forceinline__ void add(int i, unsigned long long n) const {
+    if (lead) __hip_atomic_fetch_add((jade_prof_lds_u64*)(__SIZE_TYPE__)(row + 8u * (uint32_t)i), n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
   }
   __device__ __forceinline__ void lap(int i) {
     const unsigned long long now = __builtin_amdgcn_s_memtime();
-    v[i] += now - last;
+    add(i, now - last);
     last = now;
   }
-  __device__ __forceinline__ void count(int i, unsigned long long n = 1) { v[i] += n; }
+  __device__ __forceinline__ void count(int i, unsigned long long n = 1) const { add(i, n); }
+  __device__ __forceinline__ unsigned long long get(int i) const { return *(jade_prof_lds_u64*)(__SIZE_TYPE__)(row + 8u * (uint32_t)i); }
   static __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
 };
 #define PROF_LAP(pr, i) (pr).lap(i)
@@ -603,7 +614,13 @@ static_assert((JADE_HQ & (JADE_HQ - 1)) == 0 && JADE_HQ >= 128, "JADE_HQ");
 #define JADE_HQ_BATCH 64 /* candidates waiting that trigger a resolve pass */
 #endif
 
+#ifndef JADE_PREFETCH
+#define JADE_PREFETCH 0 /* 1: a walk unit ends by requesting the record of the node the walk goes to next (WalkState.pre), so that its latency passes while the wave pushes leaves, picks its next kind of work, tests triangles */
+#endif
 struct WalkState {
+#if JADE_PREFETCH
+  NodeRec pre;      // the record of `cur`, requested when cur was set
+#endif
   RayOD od;         // origin and normalize(d)
   uint32_t skipx;   // as in RayState
   uint32_t cur;     // internal-node ref, a leaf ref (a far child off the stack), or JADE_REF_NONE = walk finished
@@ -630,11 +647,19 @@ static __device__ __forceinline__ void walk_begin(WalkState& r, const LdsStack& 
   lds_put(stk, TW_BEST_SEQ, 0xffffffffu);
   lds_put(stk, TW_BEST_REF, 0xffffffffu);
   lds_st_v(stk.col + TW_FINISHED * JADE_COL_STRIDE, 0u);
+#if JADE_PREFETCH
+  r.pre = node_fetch<JADE_TRACE_TOP_NODES>(r.cur, S, stk);
+#endif
 }
 // One unit of the walk for a lane whose walk has not ended.  Returns the leaf met (0 = none): the caller queues it.
 template <bool GENERAL>
 static __device__ __forceinline__ uint32_t walk_step(WalkState& r, const DevScene& S, const LdsStack& stk, uint32_t& vcnt) {
+#if JADE_PREFETCH
+  const uint32_t leafv = node_decide<GENERAL, 0, TW_DUMMY>(r.pre, r.cur, r.sp, r.od, stk, true, vcnt, &r.inv);
+  if (r.cur != JADE_REF_NONE) r.pre = node_fetch<JADE_TRACE_TOP_NODES>(r.cur, S, stk);
+#else
   const uint32_t leafv = node_core<GENERAL, 0, TW_DUMMY, JADE_TRACE_TOP_NODES>(r.cur, r.sp, r.od, S, stk, true, vcnt, &r.inv);
+#endif
   return (leafv & 15u) != 0 ? leafv : 0u;  // (an empty leaf cannot happen for a valid BVH)
 }
 
