@@ -212,9 +212,11 @@ def main():
     gather_ms = (time.perf_counter() - g0) * 1e3
     if world == 1 and part_world == 1:
         frame = D.gather_framebuffer(tiles, width, height)
-    frame_ok = True
+    frame_ok, frame_sha = True, None
     if rank == 0 and frame is not None:
         frame_ok = bool(torch.isfinite(frame).all().item()) and tuple(frame.shape) == (height, width, 3)
+        import hashlib
+        frame_sha = hashlib.sha256(frame.detach().cpu().contiguous().numpy().tobytes()).hexdigest()[:32]  # the gathered linear frame, bit for bit
 
     cls_keys = ("rays_primary", "rays_shadow", "rays_env", "rays_indirect", "rays_mirror", "rays_refract")
     vals = torch.tensor([float(st.rays_primary + st.rays_secondary), float(st.nodes_visited), float(st.tris_tested),
@@ -334,6 +336,7 @@ def main():
             "rays_by_call_site": {k[5:]: float(vals[6 + i].item()) for i, k in enumerate(cls_keys)},
             "gather_ms": gather_ms,
             "frame_ok": frame_ok,
+            "frame_sha256": frame_sha,   # equal for any number of ranks at equal total samples (tests/test_gpu_bench.py)
             # host waits for the device: per step (the fused first pass, then ONE batch of up to 32 shade / trace passes that
             # stops itself at the carry-over point), and in the flush that finishes the last paths of the render
             "host_syncs_per_step": syncs_in_steps / max(args.steps, 1),

@@ -75,6 +75,11 @@ struct DevScene {
   int32_t n_tris, n_emit;
   uint32_t root_ref;
   uint32_t top_k;             // internal nodes [0, top_k) are the ones k_trace stages in LDS (largest boxes first)
+  // BSSRDF exit-point search (jade_shade.h, begin_bounce): guide_obj[o] = {first entry of object o's guide, cells Gn (a power of
+  // two; 0 = no guide, search as the reference does)}; guide[first + c] = the first triangle i (original order) of the object
+  // with fl(c / Gn * A) <= prefix[i], c = 0 .. Gn + 1
+  const uint32_t* guide;
+  const uint2* guide_obj;
   uint32_t general_walk;      // an internal node lacks a child (the reference's "child 0"): every wave takes the general node step (jade_trace.h)
 };
 

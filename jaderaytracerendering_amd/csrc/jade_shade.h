@@ -255,14 +255,34 @@ static __device__ bool begin_bounce(const DevScene& S, const Px& px, ShadeCtx& c
       }
       // ---- BSSRDF, PathTrace.cu:1029-1178 ----
       const jade_obj_seg seg = S.segs[ot->obj_idx];
-      float random_idx = jade_rand(&c.rng) * S.prefix[seg.end_idx];
+      const float u_area = jade_rand(&c.rng);
+      float random_idx = u_area * S.prefix[seg.end_idx];
       int left = seg.begin_idx, right = seg.end_idx, middle = 0;
-      while (left < right - 1) {
-        middle = (left + right) / 2;
-        float pm = S.prefix[middle];
-        if (random_idx <= pm) right = middle;
-        else if (random_idx >= pm) left = middle;
-        else break;
+      const uint2 gd = S.guide_obj[ot->obj_idx];
+      if (gd.y != 0u) {
+        // The reference bisects prefix[] (:1031-1048): ~17 DEPENDENT loads, the longest latency chain of this kernel, and what
+        // it returns is not the boundary but the LAST midpoint it looked at.  Both are reproduced without the chain: the
+        // boundary b = the first i with random_idx <= prefix[i] comes from a guide table (jade_scene_create: prefix is
+        // checked to be finite and non-decreasing, so "random_idx <= prefix[mid]" is "mid >= b"; the cell's bounds hold
+        // because rounding is monotone: c / Gn <= u implies fl(c / Gn * A) <= fl(u * A)), then the bisection is replayed
+        // on indices alone.
+        const uint32_t cell = (uint32_t)(u_area * (float)gd.y);  // u in [0, 1], Gn a power of two: exact
+        const uint2 range = *reinterpret_cast<const uint2*>(S.guide + gd.x + cell);  // (8-B alignment not guaranteed: two dwords)
+        uint32_t b = range.x;
+        while (b < range.y && !(random_idx <= S.prefix[b])) ++b;
+        while (left < right - 1) {
+          middle = (left + right) / 2;
+          if ((uint32_t)middle >= b) right = middle;
+          else left = middle;
+        }
+      } else {
+        while (left < right - 1) {
+          middle = (left + right) / 2;
+          float pm = S.prefix[middle];
+          if (random_idx <= pm) right = middle;
+          else if (random_idx >= pm) left = middle;
+          else break;
+        }
       }
       middle = S.mapping[middle];
       float rand_x = jade_rand(&c.rng);

@@ -56,3 +56,27 @@ def test_bench_json_contract():
     assert cb["kind"] == "port" and cb["unit"] == "Mray/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
     # samples rendered in the timed region: 2 steps x 16 spp x 96 x 64 pixels
     assert d["samples"] == 2 * 16 * 96 * 64
+
+
+def _bench_line(args, timeout=900):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_four_rank_rehearsal_gathers_the_one_rank_frame():
+    """The multi-rank flow of bench.py at the benchmark's frame size, rehearsed on the one GPU: four rank processes (the
+    box admits at most six processes on its card, and this test session is one of them; the driver's real run is eight
+    ranks, one per GPU, over RCCL), tiles dealt (tx + ty) % 4, each rank holding a quarter of the memory, the frame
+    gathered through torch.distributed (gloo here).  Samples per step scale with the ranks (weak scaling), so four
+    ranks x 12 spp = one rank x 48 spp: the gathered frame must be the one-rank frame bit for bit, and so must the rays."""
+    common = ["--config", "C3", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extras"]
+    one = _bench_line(common + ["--spp-per-step", "48"])
+    six = _bench_line(common + ["--gpus", "4", "--dist-backend", "gloo", "--spp-per-step", "12"])
+    assert one["n_gpus"] == 1 and six["n_gpus"] == 4 and six["rehearsal_all_ranks_on_one_gpu"] is True
+    assert one["config"]["spp_per_step"] == six["config"]["spp_per_step"] == 48
+    assert one["frame_ok"] and six["frame_ok"] and one["frame_sha256"] and one["frame_sha256"] == six["frame_sha256"]
+    assert one["rays"] == six["rays"] and one["samples"] == six["samples"] == 48 * 1920 * 1080
+    assert one["rays_by_call_site"] == six["rays_by_call_site"]
