@@ -48,7 +48,7 @@
 // (the node records with the largest boxes: jade_scene_create orders the internal nodes by box area so that any prefix
 // is a connected top).  A visit of such a node is four ds_read_b128 of a plane layout instead of four 16-B gathers
 // through the vector-memory path: 40 % of k_trace's node visits on C3 with 160 nodes.  Measured: a
-// few per cent, with the FIFO form of k_trace (bound by VALU issue) as with the final one (bound by latency); one
+// few per cent, with the FIFO form of k_trace as with the final one; one
 // 1024-thread workgroup per CU with 768-1 272 nodes staged did not pay either time.
 #ifndef JADE_TRACE_BLOCK
 #define JADE_TRACE_BLOCK 256

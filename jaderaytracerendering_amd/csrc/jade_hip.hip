@@ -508,7 +508,7 @@ static __device__ __forceinline__ void nt_st4(float4* p, float x, float y, float
   NT_ST(reinterpret_cast<jade_v4f*>(p), v);
 }
 #ifndef JADE_TRACE_WAVES
-#define JADE_TRACE_WAVES 4 /* waves per SIMD the register allocation leaves room for: k_trace's LDS (34 KB per block) admits 4 blocks per CU; 4 and 5 blocks run at the same speed (the kernel is bound by latency and by L2 line fetches, not by issue: DESIGN.md 3.4) */
+#define JADE_TRACE_WAVES 5 /* waves per SIMD the register allocation leaves room for: 5 = at most 96 VGPRs (12 bytes of scratch) and 5 x 31 KB of LDS per CU.  Round 3, same process, C3 / statue close-up: 4 waves (102 VGPRs) 133.6 / 1037 ms of k_trace per 256-spp step, 5 waves 126.9 / 983 (round 2's "5 and 6 blocks per CU are no faster" was measured on a 102-VGPR build, which the hardware never ran at more than 4) */
 #endif
 __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(DevScene S, PathState P, const uint32_t* queue, QueueCtl* qc,
                                                            uint32_t* spill, DevCounters* ctr, uint32_t chunk) {
@@ -573,7 +573,7 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
       wb = true;
     }
     // ---- once enough lanes are idle (or all are): write their results back and refill them.  Both are done for >=
-    // JADE_REFILL_MIN lanes at a time, not whenever a single ray ends: the kernel is bound by VALU issue and a block that
+    // JADE_REFILL_MIN lanes at a time, not whenever a single ray ends: a block of code that
     // runs for one lane costs as much as for 64.
     const unsigned long long idle = __ballot(!active);
     const int n_idle = __popcll(idle);
@@ -923,6 +923,223 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_LIGHT_WAVES) void k_light(De
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// k_light_packet: k_light with the wave's rays walked together (jade_trace.h, "Packet form").  What k_light traces - camera
+// rays of 64 neighbouring pixels, their reflections off the mirror floor - is as coherent as rays get, and its time is the
+// traversal (two thirds of its instructions): one scalar cursor and stack per wave, the node and pair records through
+// scalar loads, no per-lane stack / FIFO / column in LDS.  A wave alternates two phases so that a packet holds one kind of
+// ray: all its lanes' camera rays, then the mirror rays those produced.  Shading statements, draw order and sums are those
+// of k_light (and of shade_record<true> + k_trace): the same bits (test_result_independent_of_shade_schedule).
+// ---------------------------------------------------------------------------------------------------------------
+#ifndef JADE_PACKET_WAVES
+#define JADE_PACKET_WAVES 5
+#endif
+__global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_PACKET_WAVES) void k_light_packet(DevScene S, PathState P, RenderConst R, const int32_t* tile_ids,
+                                                                                   uint32_t target_spp, uint32_t* heavy_regions, uint32_t region_cap,
+                                                                                   uint32_t* wave_counts, DevCounters* ctr) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds_stack[JADE_TRACE_BLOCK / 64][8 * (JADE_PACKET_MAX_DEPTH + 1)];
+  __shared__ uint32_t sh_ctr[JADE_TRACE_BLOCK / 64][8];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t stack = lds_addr_of(&lds_stack[w][0]);
+  const int npix = P.npix;
+  const size_t sn = (size_t)P.sum_lanes * (size_t)P.npx;
+  uint32_t vcnt = 0, tcnt = 0, n_mirror = 0;
+  ShadeCtx c;
+  c.n_emit_rays = 0;
+  c.c_primary = c.c_shadow = c.c_shaded = c.c_samples = c.c_cls = 0;
+  const uint32_t wave_id = blockIdx.x * (JADE_TRACE_BLOCK / 64) + (uint32_t)w;
+  uint32_t* const my_region = heavy_regions + (size_t)wave_id * region_cap;
+  uint32_t n_deferred = 0;
+  for (size_t base = (size_t)wave_id * 64; base < (size_t)npix; base += (size_t)gridDim.x * JADE_TRACE_BLOCK) {
+    const size_t p64 = base + (size_t)lane;
+    const bool have = p64 < (size_t)npix;
+    const int p = have ? (int)p64 : 0;
+    const uint4 hdr0 = P.hdr[p];
+    const uint32_t word = hdr0.z;
+    uint32_t st = have ? (word & 255u) : (uint32_t)ST_INVALID;
+    const uint32_t rec_m = (uint32_t)p / (uint32_t)P.npx;
+    const int home_pix = (int)((uint32_t)p - rec_m * (uint32_t)P.npx);
+    const int tid0 = tile_ids[home_pix >> 8];
+    uint32_t done = hdr0.y;
+    bool defer = false;
+    bool mine = st == ST_IDLE;  // (a record in the middle of a carried-over path goes to k_shade untouched, as in k_light)
+    const bool untouched = have && st != ST_IDLE && st != ST_INVALID;
+    if (untouched) defer = true;
+    c.rng = hdr0.x;
+    c.depth = 0;
+    c.flags = 0;
+    c.thr = jv(1, 1, 1);
+    c.acc = jv(0, 0, 0);
+    c.le = jv(0, 0, 0);
+    c.obj = 0;
+    c.src = jv(0, 0, 0);
+    c.out = jv(0, 0, 0);
+    RegPx rp;
+    rp.d = jv(0, 0, 1);
+    rp.o = jv(0, 0, 0);
+    rp.hp = jv(0, 0, 0);
+    rp.h = -1;
+    rp.sk = -1;
+    bool finished = false;
+    jvec3 color = jv(0, 0, 0), l_final = jv(0, 0, 0);
+    for (;;) {
+      // ---- every lane without a ray advances until it has one (camera or mirror), is out of samples, or parks
+      if (mine && st != ST_PRIMARY && st != ST_MIRROR) {
+        for (;;) {
+          if (finished) {
+            const NextSample cs = next_sample_mh(P, rec_m, (uint32_t)home_pix, done);  // the sample that just ended
+            const size_t si = (size_t)(cs.sidx % JADE_SAMPLE_LANES) * (size_t)P.npx + (size_t)cs.pixel;
+            st3w(P.sum, sn, si, jv_add(ld3w(P.sum, sn, si), color));
+            done += 1;
+            c.c_samples += 1;
+            finished = false;
+            st = ST_IDLE;
+          }
+          if (st == ST_VERTEX) {
+            if (!lean_can_shade(&S.tris[c.obj])) {  // jade / diffuse / glass: k_shade continues from here
+              defer = true;
+              mine = false;
+              break;
+            }
+            if (begin_bounce_lean(S, rp, c, &l_final)) {  // the mirror ray is in rp
+              n_mirror += 1;
+              st = ST_MIRROR;
+              break;
+            }
+            color = jv_add(c.le, jv_add(c.acc, jv_mul(c.thr, l_final)));
+            finished = true;
+            continue;
+          }
+          // ST_IDLE: the next sample of this record; samples of out-of-image pixels (edge tiles) are skipped
+          int x, y;
+          NextSample ns = next_sample_mh(P, rec_m, (uint32_t)home_pix, done);
+          while (ns.sidx < target_spp && !pixel_xy_t(R, ns.pixel == home_pix ? tid0 : tile_ids[ns.pixel >> 8], ns.pixel, &x, &y)) {
+            done += 1;
+            ns = next_sample_mh(P, rec_m, (uint32_t)home_pix, done);
+          }
+          if (ns.sidx >= target_spp) {  // nothing left for this record in this step
+            mine = false;
+            break;
+          }
+          // camera ray, PathTrace.cu:1428-1437 (the statements of shade_record)
+          c.rng = jade_rng_seed((uint32_t)x, (uint32_t)y, R.frame + ns.sidx);
+          float fx = (float)x + jade_rand(&c.rng);
+          double lo = -1.0 + R.two_over_w * ((double)fx - 0.5);
+          float left_offset = (float)(lo * R.aspect);
+          float fy = (float)y + jade_rand(&c.rng);
+          float up_offset = (float)(-1.0 + R.two_over_h * ((double)fy - 0.5));
+          jvec3 dir = jade_transform(jv(left_offset, up_offset, -1.5f), 0.0f, R.cam);
+          dir = jv_normalize(dir);
+          rp.set_origin(jv(P.eye[0], P.eye[1], P.eye[2]), JADE_SKIP_CAMERA);
+          rp.set_dir(0, dir);
+          c.c_primary += 1;
+          c.depth = 0;
+          c.flags = 0;
+          st = ST_PRIMARY;
+          break;
+        }
+      }
+      const bool cam = mine && st == ST_PRIMARY, mir = mine && st == ST_MIRROR;
+      const unsigned long long mc = __ballot(cam), mm = __ballot(mir);
+      if ((mc | mm) == 0ull) break;  // every lane is out of samples or parked
+      // ---- one packet of ONE kind of ray, the kind more lanes hold (a lane with the other kind waits: a wave whose pixels
+      // all see the floor alternates camera packets and mirror packets of 64 rays each)
+      const bool go = __popcll(mc) >= __popcll(mm) ? cam : mir;
+      {
+        const jvec3 o = rp.o, d = rp.d;
+        const bool exact = !(finite_f(1.0f / d.x) && finite_f(1.0f / d.y) && finite_f(1.0f / d.z)) || !finite_f(o.x) || !finite_f(o.y) || !finite_f(o.z);
+        PacketBest best;
+        if (go) vcnt += 1;  // the root record
+        if (S.general_walk || __ballot(go && exact) != 0ull) packet_trace<true>(S, stack, lane, go, o, d, rp.sk, vcnt, tcnt, best);
+        else packet_trace<false>(S, stack, lane, go, o, d, rp.sk, vcnt, tcnt, best);
+        if (go) {
+          rp.h = (int32_t)best.index;
+          rp.hp = best.point;
+        }
+      }
+      // ---- fold the result in (shade_record's part (a))
+      if (go) {
+        if (st == ST_PRIMARY) {
+          if (rp.h < 0) {
+            color = sample_hdr(S, rp.d);  // PathTrace.cu:1443-1445
+            finished = true;
+            st = ST_IDLE;
+          } else {
+            c.le = V3(S.tris[rp.h].emissive);
+            c.thr = jv(1, 1, 1);
+            c.acc = jv(0, 0, 0);
+            c.depth = 0;
+            c.obj = rp.h;
+            c.src = rp.hp;
+            c.out = jv_neg(rp.d);
+            st = ST_VERTEX;
+          }
+        } else {  // ST_MIRROR
+          c.stage = ST_MIRROR;
+          const int rr = consume_mirror(S, rp, c, &l_final);
+          if (rr == CONSUME_VERTEX) {
+            st = ST_VERTEX;
+          } else {
+            color = jv_add(c.le, jv_add(c.acc, jv_mul(c.thr, l_final)));
+            finished = true;
+            st = ST_IDLE;
+          }
+        }
+      }
+    }
+    // ---- store what the next kernel needs
+    if (have && st != ST_INVALID && !untouched) {  // (a carried-over record was not touched)
+      P.hdr[p] = make_uint4(c.rng, done, st == ST_VERTEX ? ST_VERTEX | (c.depth << 8) | (c.flags << 16) : (uint32_t)ST_IDLE, 0u);
+      if (st == ST_VERTEX) {  // parked: the path context, as shade_record stores it for this stage
+        float4* cx = P.ctx + (size_t)p * 5;
+        float* cf = reinterpret_cast<float*>(cx);
+        cf[0] = c.thr.x; cf[1] = c.thr.y; cf[2] = c.thr.z; cf[3] = __int_as_float(c.obj);
+        cf[4] = c.acc.x; cf[5] = c.acc.y; cf[6] = c.acc.z;
+        cx[2] = make_float4(c.le.x, c.le.y, c.le.z, c.src.x);
+        cx[3] = make_float4(c.src.y, c.src.z, c.out.x, c.out.y);
+        cf[16] = c.out.z;
+      }
+    }
+    // ---- hand-over: append to this wave's region
+    {
+      const unsigned long long dm = __ballot(defer);
+      if (defer) my_region[n_deferred + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull))] = (uint32_t)p;
+      n_deferred += (uint32_t)__popcll(dm);
+    }
+  }
+  if (lane == 0) wave_counts[wave_id] = n_deferred;
+  // ---- work counters, as k_light
+  {
+    const uint32_t s0 = (uint32_t)wave_sum_u32(c.c_primary), s2 = (uint32_t)wave_sum_u32(c.c_shaded), s3 = (uint32_t)wave_sum_u32(c.c_samples);
+    const unsigned long long s6 = wave_sum_u32(n_mirror);
+    const unsigned long long sv = wave_sum_u32(vcnt), stt = wave_sum_u32(tcnt);
+    if (lane == 0) {
+      sh_ctr[w][0] = s0;
+      sh_ctr[w][1] = 0;
+      sh_ctr[w][2] = s2;
+      sh_ctr[w][3] = s3;
+      sh_ctr[w][4] = 0;
+      sh_ctr[w][5] = 0;
+      sh_ctr[w][6] = (uint32_t)s6;
+      sh_ctr[w][7] = 0;
+      DevCounters* cs = ctr + (blockIdx.x % JADE_CTR_SHARDS);
+      if (sv) atomicAdd(&cs->nodes_visited, sv);
+      if (stt) atomicAdd(&cs->tris_tested, stt);
+      if (sv) atomicAdd(&cs->nodes_inline, sv);
+      if (stt) atomicAdd(&cs->tris_inline, stt);
+      if (s0 + s6) atomicAdd(&cs->rays_inline, (unsigned long long)s0 + s6);
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+      unsigned long long t = 0;
+      for (int i = 0; i < JADE_TRACE_BLOCK / 64; ++i) t += sh_ctr[i][threadIdx.x];
+      DevCounters* cs = ctr + (blockIdx.x % JADE_CTR_SHARDS);
+      const int i = (int)threadIdx.x, wordi = i < 2 ? i : i < 4 ? i + 2 : i + 4;
+      if (t) atomicAdd(reinterpret_cast<unsigned long long*>(cs) + wordi, t);
+    }
+  }
+}
+
 // Hand-over list of k_light: every wave filled a region of its own; one block turns the per-wave counts into offsets
 // (and the total into qc->heavy, where k_shade reads it), then each region is copied to its place in the dense list.
 __global__ __launch_bounds__(1024) void k_heavy_scan(uint32_t* wave_counts, uint32_t n_waves, QueueCtl* qc) {
@@ -1060,6 +1277,7 @@ struct Tunables {
   int records_per_pixel = 0;  // JADE_RECORDS_PER_PIXEL: test hook, results must not depend on it
   int trace_blocks_per_cu = 0;  // JADE_TRACE_BLOCKS_PER_CU: occupancy sweeps
   bool force_rccl = false;    // JADE_FORCE_RCCL=1 (tests): the RCCL path for a single share too
+  bool light_packet = true;   // JADE_LIGHT_PACKET=0: the fused first pass walks its rays per lane (k_light) instead of as packets
   void read() {
     auto flag0 = [](const char* n) { const char* e = getenv(n); return e && atoi(e) == 0; };
     auto flag1 = [](const char* n) { const char* e = getenv(n); return e && atoi(e) > 0; };
@@ -1073,6 +1291,7 @@ struct Tunables {
     if (const char* e = getenv("JADE_RECORDS_PER_PIXEL")) records_per_pixel = atoi(e);
     if (const char* e = getenv("JADE_TRACE_BLOCKS_PER_CU")) trace_blocks_per_cu = atoi(e);
     force_rccl = getenv("JADE_FORCE_RCCL") != nullptr;
+    light_packet = !flag0("JADE_LIGHT_PACKET");
   }
 };
 
@@ -1081,7 +1300,7 @@ struct jade_scene {
   Tunables tun;
   hipStream_t stream = nullptr;
   DevScene dev{};
-  DevBuf b_nodes, b_tverts, b_tris, b_emit, b_mapping, b_prefix, b_segs, b_env;
+  DevBuf b_nodes, b_tverts, b_tris, b_emit, b_mapping, b_prefix, b_segs, b_env, b_guide, b_guide_obj;
   int n_emit = 0;
   int bvh_depth = 0;
   // render state
@@ -1093,6 +1312,7 @@ struct jade_scene {
   std::vector<int32_t> tile_ids;
   int trace_blocks = 0;
   int light_blocks = 0;       // persistent grid of k_light
+  int packet_blocks = 0;      // ... and of k_light_packet (0: the tree is too deep for the packet form)
   int64_t spp_done = 0;
   bool tail_pending = false;  // the last step left its longest paths unfinished (jade_render_flush)
   hipEvent_t ev[7] = {};      // run_passes' timing events, made once (ev0, ev1, ta, tb, sa, sb, sm)
@@ -1391,6 +1611,40 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
     }
   }
 
+  // Guide tables for the BSSRDF exit-point search (jade_shade.h, begin_bounce; PathTrace.cu:1031-1048).  Per object with
+  // finite, non-decreasing prefix areas: Gn = the power of two >= 4 x its triangles cells, guide[c] = the first triangle i with
+  // fl(c / Gn * A) <= prefix[i] - the product rounded once to fp32, as the kernel's `u * A` is (this file is built
+  // -ffp-contract=off like the device code) - for c = 0 .. Gn, and one more entry so that cell Gn (u == 1) has an upper bound.
+  // An object whose prefix areas are not monotone or not finite gets Gn = 0: the kernel then bisects as the reference does.
+  std::vector<uint32_t> guide;
+  std::vector<uint2> guide_obj((size_t)d->n_objects, make_uint2(0u, 0u));
+  for (int o = 0; o < d->n_objects; ++o) {
+    const int b = d->obj_segs[o].begin_idx, e = d->obj_segs[o].end_idx;
+    bool ok = true;
+    for (int i = b; i <= e && ok; ++i) {
+      const float v = d->prefix_area[i];
+      ok = v == v && v >= 0.0f && v < 3.0e38f && (i == b || v >= d->prefix_area[i - 1]);
+    }
+    const size_t nt = (size_t)(e - b + 1);
+    if (!ok || nt < 2 || nt > ((size_t)1 << 21)) continue;
+    uint32_t gn = 1;
+    while (gn < 4 * nt) gn <<= 1;
+    const float A = d->prefix_area[e];
+    const size_t first = guide.size();
+    guide.resize(first + gn + 2);
+    int i = b;
+    for (uint32_t c = 0; c <= gn; ++c) {
+      const float u = (float)c / (float)gn;  // exact: both are powers of two apart
+      volatile float x = u * A;              // one rounding (volatile: no excess precision, whatever the host compiler does)
+      const float xv = x;
+      while (i < e && !(xv <= d->prefix_area[i])) ++i;
+      guide[first + c] = (uint32_t)i;
+    }
+    guide[first + gn + 1] = guide[first + gn];
+    guide_obj[(size_t)o] = make_uint2((uint32_t)first, gn);
+  }
+  if (guide.empty()) guide.push_back(0u);
+
   jade_scene* s = new (std::nothrow) jade_scene();
   if (!s) return fail(JADE_ERR_NOMEM, "out of memory");
   s->device = device_id;
@@ -1406,6 +1660,8 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
   if (e == hipSuccess) e = upload(s->b_prefix, d->prefix_area, (size_t)d->n_triangles, s->stream);
   if (e == hipSuccess) e = upload(s->b_segs, d->obj_segs, (size_t)d->n_objects, s->stream);
   if (e == hipSuccess) e = upload(s->b_env, d->env_rgb, (size_t)3 * d->env_width * d->env_height, s->stream);
+  if (e == hipSuccess) e = upload(s->b_guide, guide.data(), guide.size(), s->stream);
+  if (e == hipSuccess) e = upload(s->b_guide_obj, guide_obj.data(), guide_obj.size(), s->stream);
   if (e == hipSuccess) e = s->b_ctl.alloc(sizeof(QueueCtl) * JADE_CTL_RING);
   if (e == hipSuccess) e = s->b_ctr.alloc(sizeof(DevCounters) * JADE_CTR_SHARDS);
   if (e != hipSuccess) {
@@ -1420,6 +1676,8 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
   s->dev.prefix = s->b_prefix.as<float>();
   s->dev.segs = s->b_segs.as<jade_obj_seg>();
   s->dev.env = s->b_env.as<float>();
+  s->dev.guide = s->b_guide.as<uint32_t>();
+  s->dev.guide_obj = s->b_guide_obj.as<uint2>();
   s->dev.env_w = d->env_width;
   s->dev.env_h = d->env_height;
   s->dev.n_tris = d->n_triangles;
@@ -1457,6 +1715,14 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
   if (light_cu < 1) light_cu = 1;
   if (light_cu > per_cu) light_cu = per_cu;  // the stack spill area is sized for the k_trace grid
   s->light_blocks = prop.multiProcessorCount * light_cu;
+  if (depth <= JADE_PACKET_MAX_DEPTH) {
+    int pk_cu = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&pk_cu, k_light_packet, JADE_TRACE_BLOCK, 0);
+    if (pk_cu < 1) pk_cu = 1;
+    if (pk_cu > 8) pk_cu = 8;
+    s->packet_blocks = prop.multiProcessorCount * pk_cu;
+  }
+  if (s->tun.log_passes) fprintf(stderr, "[jade] first pass: k_light %d blocks, k_light_packet %d blocks (tree depth %d)\n", s->light_blocks, s->packet_blocks, depth);
   *out = s;
   return JADE_OK;
 }
@@ -1498,9 +1764,10 @@ static int setup_state(jade_scene* s, int npx, int rpp, int nslots, int sum_lane
   P.slot = (float4*)(b + o_slot);
   HIP_TRY(s->b_queue.alloc(K * N * 4));
   // b_active[0] doubles as k_light's per-wave hand-over regions: up to 64 records of slack per wave of its grid
-  HIP_TRY(s->b_active[0].alloc((N + (size_t)s->light_blocks * JADE_TRACE_BLOCK + 64) * 4));
+  const size_t first_pass_blocks = (size_t)std::max(s->light_blocks, s->packet_blocks);
+  HIP_TRY(s->b_active[0].alloc((N + first_pass_blocks * JADE_TRACE_BLOCK + 64) * 4));
   HIP_TRY(s->b_active[1].alloc(N * 4));
-  HIP_TRY(s->b_wavecnt.alloc((size_t)2 * s->light_blocks * (JADE_TRACE_BLOCK / 64) * 4));
+  HIP_TRY(s->b_wavecnt.alloc((size_t)2 * first_pass_blocks * (JADE_TRACE_BLOCK / 64) * 4));
   if (!s->b_spill.p)
     HIP_TRY(s->b_spill.alloc((size_t)(JADE_BVH_STACK_CAPACITY - JADE_LDS_STACK) * s->trace_blocks * JADE_TRACE_BLOCK * 4));
   return JADE_OK;
@@ -1762,15 +2029,20 @@ static int run_passes(jade_scene* s, int64_t from_spp, uint32_t target_spp, bool
       HIP_TRY(hipEventRecord(s->ev_light[0], s->stream));
       light_timed = true;
       {
-        const unsigned lb = (unsigned)std::min<size_t>((size_t)s->light_blocks, ((size_t)npix + JADE_TRACE_BLOCK - 1) / JADE_TRACE_BLOCK);
+        const bool packet = s->tun.light_packet && s->packet_blocks > 0;
+        const unsigned lb = (unsigned)std::min<size_t>((size_t)(packet ? s->packet_blocks : s->light_blocks), ((size_t)npix + JADE_TRACE_BLOCK - 1) / JADE_TRACE_BLOCK);
         const uint32_t n_waves = lb * (JADE_TRACE_BLOCK / 64);
         // a wave takes every n_waves-th chunk of 64 records: its region must hold all of them
         const uint32_t region_cap = (uint32_t)((((size_t)npix + 63) / 64 + n_waves - 1) / n_waves) * 64u;
         if ((size_t)region_cap * n_waves > s->b_active[0].bytes / 4 || (size_t)2 * n_waves * 4 > s->b_wavecnt.bytes)
           return fail(JADE_ERR_DEVICE, "hand-over regions do not fit (internal sizing error)");
-        hipLaunchKernelGGL(k_light, dim3(lb), dim3(JADE_TRACE_BLOCK), 0, s->stream, s->dev, s->ps, s->rc, s->b_tiles.as<int32_t>(), target_spp,
-                           s->b_active[0].as<uint32_t>(), region_cap, s->b_wavecnt.as<uint32_t>(), s->b_spill.as<uint32_t>(),
-                           s->b_ctr.as<DevCounters>());
+        if (packet)
+          hipLaunchKernelGGL(k_light_packet, dim3(lb), dim3(JADE_TRACE_BLOCK), 0, s->stream, s->dev, s->ps, s->rc, s->b_tiles.as<int32_t>(), target_spp,
+                             s->b_active[0].as<uint32_t>(), region_cap, s->b_wavecnt.as<uint32_t>(), s->b_ctr.as<DevCounters>());
+        else
+          hipLaunchKernelGGL(k_light, dim3(lb), dim3(JADE_TRACE_BLOCK), 0, s->stream, s->dev, s->ps, s->rc, s->b_tiles.as<int32_t>(), target_spp,
+                             s->b_active[0].as<uint32_t>(), region_cap, s->b_wavecnt.as<uint32_t>(), s->b_spill.as<uint32_t>(),
+                             s->b_ctr.as<DevCounters>());
         hipLaunchKernelGGL(k_heavy_scan, dim3(1), dim3(1024), 0, s->stream, s->b_wavecnt.as<uint32_t>(), n_waves, qc);
         hipLaunchKernelGGL(k_heavy_pack, dim3(n_waves), dim3(256), 0, s->stream, s->b_active[0].as<uint32_t>(), region_cap,
                            s->b_wavecnt.as<uint32_t>(), n_waves, s->b_active[1].as<uint32_t>());

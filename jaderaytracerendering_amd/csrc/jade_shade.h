@@ -267,9 +267,10 @@ static __device__ bool begin_bounce(const DevScene& S, const Px& px, ShadeCtx& c
         // because rounding is monotone: c / Gn <= u implies fl(c / Gn * A) <= fl(u * A)), then the bisection is replayed
         // on indices alone.
         const uint32_t cell = (uint32_t)(u_area * (float)gd.y);  // u in [0, 1], Gn a power of two: exact
-        const uint2 range = *reinterpret_cast<const uint2*>(S.guide + gd.x + cell);  // (8-B alignment not guaranteed: two dwords)
-        uint32_t b = range.x;
-        while (b < range.y && !(random_idx <= S.prefix[b])) ++b;
+        const uint32_t* gp = S.guide + gd.x + cell;
+        const uint32_t b_hi = gp[1];
+        uint32_t b = gp[0];
+        while (b < b_hi && !(random_idx <= S.prefix[b])) ++b;
         while (left < right - 1) {
           middle = (left + right) / 2;
           if ((uint32_t)middle >= b) right = middle;

@@ -108,7 +108,8 @@ struct TraceProf {};
 // (bank-conflict free): words [0, JADE_LDS_STACK) are the traversal stack, then the leaf FIFO, then the JADE_LDS_STATE
 // words that hold the parts of the ray state the triangle test does not read (see RayState).
 //
-// The node step is bound by instruction issue, and a third of it was address arithmetic for these words (index -> * 256
+// What a unit of work costs is the instructions a wave issues for it (round 3 profile, DESIGN.md 3.4: a unit is ~150 instructions
+// and ~2,700 clocks, a third of them waiting for its one record), and a third of the node step was address arithmetic for these words (index -> * 256
 // -> select -> * 4 + base, per access).  So positions are kept AS LDS byte addresses: the stack pointer is the address
 // of the next free level, the FIFO counters advance in units of one column word, and the column array is 4 KB-aligned
 // so that a FIFO slot's address is one v_and_or of the counter and the FIFO's base.
@@ -153,7 +154,7 @@ static __device__ __forceinline__ void lds_putf(const LdsStack& s, int word, flo
 static __device__ __forceinline__ float lds_getf(const LdsStack& s, int word) { return jade_u2f(lds_get(s, word)); }
 
 // Two lanes of packed fp32 (v_pk_add/mul/fma_f32: full rate, IEEE per component, so the
-// values are those of the scalar statements).  The kernel is VALU-bound; the left/right slab
+// values are those of the scalar statements).  A unit's time follows its instruction count; the left/right slab
 // tests and the projections of p1/p2 are the same statements on two operands.
 typedef float f2 __attribute__((ext_vector_type(2)));
 static __device__ __forceinline__ f2 f2s(float s) { return f2{s, s}; }
@@ -220,7 +221,7 @@ static __device__ __forceinline__ bool finite_f(float x) { return (jade_f2u(x) &
 // small FIFO of leaf cursors — and tests triangles from the head of that FIFO.  A wave
 // iteration runs ONE of the two kinds of work for all the lanes that have some of it
 // (k_trace picks the kind with more lanes), which a lane that still walks nodes and also has
-// leaves waiting can always join.  The kernel is VALU-bound: with the kinds interleaved per
+// leaves waiting can always join.  With the kinds interleaved per
 // lane, as in a plain loop over hitBVH, each instruction runs for about a third of the lanes.
 //
 // In registers: o, normalize(d), the skip index, the node cursor, the leaf cursor, the stack pointer and the FIFO
@@ -281,7 +282,7 @@ static __device__ __forceinline__ jvec3 ray_hit_point(const LdsStack& stk) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// The two steps, straight-line.  k_trace is bound by instruction issue, and nested ifs cost it twice: every `if` is 3-4
+// The two steps, straight-line.  A wave issues one instruction at a time, of whatever kind, and nested ifs cost it twice: every `if` is 3-4
 // scalar instructions of EXEC bookkeeping in the wave's (serial) instruction stream - scalar and branch instructions
 // were 40 % of all instructions issued by the first, branchy form (round 1; git history) - and each side of it runs for
 // a part of the lanes only.  Here a decision selects values (v_cndmask) and, where it guards a store, the store's
@@ -911,3 +912,170 @@ struct WaveTrace {
     }
   }
 };
+
+// ---------------------------------------------------------------------------------------------------------------
+// Packet form (k_light, round 3): the 64 rays of a wave walk the tree TOGETHER.
+//
+// The reference never prunes against the best hit (PathTrace.cu:806-856), so the SET of nodes and leaves a ray visits does
+// not depend on the order of the walk: it is every node whose box - and whose ancestors' boxes - the ray enters ("slab
+// value > 0", :770, :835-855).  Only hitArray's tie rule sees the order (strict "<": of two equal distances the one met
+// first wins, :787, :816).  Camera rays of a 16 x 4 block of pixels, and their reflections off the flat mirror floor, enter
+// nearly the same nodes; walked per lane (RayState / WalkState above) every one of them pays for its own stack, its own
+// cursor and its own gather of the same record.  Here the wave keeps ONE cursor and ONE stack, both scalar:
+//   * a node's record is read once per wave with scalar loads (constant address space: s_load, served by the scalar cache)
+//     and every lane whose ray entered that node tests both children with the record in SGPR operands - the same
+//     statements (slab2), so the same slab values, V counted per lane exactly as before;
+//   * a stack entry is {child reference, the lanes that entered it, the lanes for which it is the FAR child, depth}: the
+//     wave goes left first and pushes the right child whenever some lane entered it.  No per-lane stack, no leaf FIFO;
+//   * a leaf is tested by the lanes that entered it, the pair record again through scalar loads (pair_core unchanged);
+//   * the order a ray itself would have met its leaves in is kept as a KEY instead of a sequence number: bit (63 - depth)
+//     of `path` says whether the node of that depth on the current path is the far child (d1 < d2 decides, :835-848) for
+//     this lane's ray.  Two leaves a ray enters differ first at their lowest common ancestor, where one lies under the near
+//     child and the other under the far one; so among equal distances the smaller key is the leaf the reference met first,
+//     and within a leaf the index order and strict "<" decide as always.  Trees deeper than 63 take the per-lane form.
+// Everything wave-uniform lives in SGPRs; the stack is a small LDS array written by lane 0 and read as a broadcast.
+// ---------------------------------------------------------------------------------------------------------------
+#define JADE_PACKET_MAX_DEPTH 63
+typedef float jade_nf4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(4))) const jade_nf4 jade_const_f4;  // constant address space + uniform address => scalar loads
+static __device__ __forceinline__ float4 ld_const_f4(jade_const_f4* p) {
+  const jade_nf4 v = *p;
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+struct PacketBest {
+  float dist;               // INF = no hit yet
+  unsigned long long key;   // the winning leaf's place in the ray's own order
+  uint32_t index;           // triangle index
+  jvec3 point;
+};
+static __device__ __forceinline__ jade_const_f4* as_const_f4(const void* base, uint32_t byte_off) {
+  return reinterpret_cast<jade_const_f4*>(reinterpret_cast<__SIZE_TYPE__>(reinterpret_cast<const char*>(base) + byte_off));
+}
+// stack entry k of the wave at LDS byte address stack + 32 k: {ref, depth, lanes lo, lanes hi, far lo, far hi, -, -}
+static __device__ __forceinline__ void packet_push(uint32_t stack, uint32_t sp, int lane, uint32_t ref, uint32_t depth, unsigned long long lanes,
+                                                   unsigned long long far) {
+  if (lane == 0) {
+    const uint32_t a = stack + 32u * sp;
+    lds_st64(a, ref, depth);
+    lds_st64(a + 8u, (uint32_t)lanes, (uint32_t)(lanes >> 32));
+    lds_st64(a + 16u, (uint32_t)far, (uint32_t)(far >> 32));
+  }
+}
+static __device__ __forceinline__ void packet_pop(uint32_t stack, uint32_t sp, uint32_t& ref, uint32_t& depth, unsigned long long& lanes,
+                                                  unsigned long long& far) {
+  const uint32_t a = stack + 32u * sp;  // the same address in every lane: a broadcast read
+  uint32_t r, d, l0, l1, f0, f1;
+  lds_ld64(a, r, d);
+  lds_ld64(a + 8u, l0, l1);
+  lds_ld64(a + 16u, f0, f1);
+  ref = __builtin_amdgcn_readfirstlane(r);
+  depth = __builtin_amdgcn_readfirstlane(d);
+  lanes = (unsigned long long)__builtin_amdgcn_readfirstlane(l0) | ((unsigned long long)__builtin_amdgcn_readfirstlane(l1) << 32);
+  far = (unsigned long long)__builtin_amdgcn_readfirstlane(f0) | ((unsigned long long)__builtin_amdgcn_readfirstlane(f1) << 32);
+}
+
+// hitBVH (PathTrace.cu:795-859) for the rays of the lanes with `active`, all lanes of the wave taking part in the control
+// flow.  o, d, skip: this lane's ray; vcnt / tcnt: this lane's counts of child records visited and triangles tested (the
+// root record is the caller's, as with ray_begin).  stack: LDS byte address of JADE_PACKET_MAX_DEPTH + 1 entries of 32 bytes
+// for this wave.  best: this lane's result (index 0xffffffff = miss).
+template <bool GENERAL>
+static __device__ __forceinline__ void packet_trace(const DevScene& S, uint32_t stack, int lane, bool active, jvec3 o, jvec3 d, int32_t skip,
+                                                    uint32_t& vcnt, uint32_t& tcnt, PacketBest& best) {
+  RayOD od;
+  const jvec3 inv = jv(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  const jvec3 dn = jv_normalize(d);
+  od.a = f2{o.x, o.y};
+  od.b = f2{o.z, dn.x};
+  od.c = f2{dn.y, dn.z};
+  const uint32_t skipu = skip < 0 ? 0x7fffffffu : (uint32_t)skip;
+  best.dist = JADE_INF_F;
+  best.key = 0ull;
+  best.index = 0xffffffffu;
+  best.point = jv(0, 0, 0);
+  unsigned long long path = 0ull;
+  const unsigned long long me = 1ull << lane;
+  uint32_t cur = S.root_ref, depth = 0, sp = 0;
+  unsigned long long lanes = __ballot(active), far = 0ull;
+  if (lanes == 0ull) return;
+  for (;;) {
+    const bool in = (lanes & me) != 0ull;
+    // this node's bit of the path: set for the lanes it is the far child for
+    const unsigned long long bit = 1ull << (63u - depth);
+    if (in) path = (far & me) ? (path | bit) : (path & ~bit);
+    if ((int32_t)cur < 0) {
+      // ---- a leaf: its pair records, one after the other, for the lanes that entered it (hitArray, :776-792)
+      const unsigned long long key = path & ~(bit - 1ull);  // (levels below this leaf hold bits of paths walked before)
+      uint32_t off = cur & 0x7ffffff0u;
+      for (uint32_t n = cur & 15u; n != 0u; --n, off += 80u) {
+        jade_const_f4* t = as_const_f4(S.tverts, off);
+        PairRec rec;
+        rec.q0 = ld_const_f4(t);
+        rec.q1 = ld_const_f4(t + 1);
+        rec.q2 = ld_const_f4(t + 2);
+        rec.q3 = ld_const_f4(t + 3);
+        rec.q4 = ld_const_f4(t + 4);
+        bool in_a = false, in_b = false;
+        uint32_t idx_a = 0;
+        if (in) pair_core(od, skipu, rec, tcnt, in_a, in_b, idx_a);
+        if (in_a || in_b) {  // the origin projects into a triangle: one test in ten; A before B (index order, strict "<")
+          const float4* tv = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.tverts) + off);
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            if (k == 0 ? in_a : in_b) {
+              float dist;
+              jvec3 P;
+              if (pair_hit(tv, k, od, &dist, &P) && (dist < best.dist || (dist == best.dist && key < best.key))) {
+                best.dist = dist;
+                best.key = key;
+                best.index = idx_a + (uint32_t)k;
+                best.point = P;
+              }
+            }
+          }
+        }
+      }
+    } else {
+      // ---- an internal node: both children's boxes from its record (hitAABB x 2, :825-832)
+      jade_const_f4* nd = as_const_f4(S.nodes, cur * 64u);
+      const float4 a = ld_const_f4(nd), b = ld_const_f4(nd + 1), c = ld_const_f4(nd + 2), r4 = ld_const_f4(nd + 3);
+      const uint32_t left = jade_f2u(r4.x), right = jade_f2u(r4.y);
+      float d1, d2;
+      slab2(od, inv, a, b, c, GENERAL, &d1, &d2);
+      bool in1, in2;
+      if (GENERAL) {
+        const bool c1 = left != JADE_REF_NONE, c2 = right != JADE_REF_NONE;  // a missing child is neither counted nor entered
+        if (in) vcnt += (c1 ? 1u : 0u) + (c2 ? 1u : 0u);
+        in1 = in && c1 && d1 > 0;
+        in2 = in && c2 && d2 > 0;
+      } else {
+        if (in) vcnt += 2u;
+        in1 = in && d1 > 0;
+        in2 = in && d2 > 0;
+      }
+      const bool both = in1 && in2, first = d1 < d2;  // near child first, :835-848: the far one is the other
+      const unsigned long long m1 = __ballot(in1), m2 = __ballot(in2);
+      const unsigned long long f1 = __ballot(both && !first), f2m = __ballot(both && first);
+      depth += 1u;
+      if (m1 != 0ull) {
+        if (m2 != 0ull) {
+          packet_push(stack, sp, lane, right, depth, m2, f2m);
+          sp += 1u;
+        }
+        cur = left;
+        lanes = m1;
+        far = f1;
+        continue;
+      }
+      if (m2 != 0ull) {
+        cur = right;
+        lanes = m2;
+        far = f2m;
+        continue;
+      }
+    }
+    // ---- nothing below: the next deferred child
+    if (sp == 0u) break;
+    sp -= 1u;
+    packet_pop(stack, sp, cur, depth, lanes, far);
+  }
+}
