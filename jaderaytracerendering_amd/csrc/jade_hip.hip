@@ -1140,6 +1140,31 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_PACKET_WAVES) void k_light_p
   }
 }
 
+// Development / tests: packet_trace on raw rays, 64 per wave in the order given; per-ray hit, distance, point, V and T.
+__global__ __launch_bounds__(JADE_TRACE_BLOCK) void k_packet_rays(DevScene S, int n, const float* origins, const float* dirs, const int32_t* skip, int32_t* hit,
+                                                                 float* dist, float* point, uint32_t* v_out, uint32_t* t_out) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds_stack[JADE_TRACE_BLOCK / 64][8 * (JADE_PACKET_MAX_DEPTH + 1)];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool have = i < n;
+  const int k = have ? i : 0;
+  const jvec3 o = jv(origins[3 * k], origins[3 * k + 1], origins[3 * k + 2]), d = jv(dirs[3 * k], dirs[3 * k + 1], dirs[3 * k + 2]);
+  const bool exact = !(finite_f(1.0f / d.x) && finite_f(1.0f / d.y) && finite_f(1.0f / d.z)) || !finite_f(o.x) || !finite_f(o.y) || !finite_f(o.z);
+  uint32_t vcnt = have ? 1u : 0u, tcnt = 0;
+  PacketBest best;
+  if (S.general_walk || __ballot(have && exact) != 0ull) packet_trace<true>(S, lds_addr_of(&lds_stack[w][0]), lane, have, o, d, skip[k], vcnt, tcnt, best);
+  else packet_trace<false>(S, lds_addr_of(&lds_stack[w][0]), lane, have, o, d, skip[k], vcnt, tcnt, best);
+  if (have) {
+    hit[i] = (int32_t)best.index;
+    dist[i] = best.dist;
+    point[3 * i] = best.point.x;
+    point[3 * i + 1] = best.point.y;
+    point[3 * i + 2] = best.point.z;
+    v_out[i] = vcnt;
+    t_out[i] = tcnt;
+  }
+}
+
 // Hand-over list of k_light: every wave filled a region of its own; one block turns the per-wave counts into offsets
 // (and the total into qc->heavy, where k_shade reads it), then each region is copied to its place in the dense list.
 __global__ __launch_bounds__(1024) void k_heavy_scan(uint32_t* wave_counts, uint32_t n_waves, QueueCtl* qc) {
@@ -2524,6 +2549,31 @@ int jade_trace_rays(jade_scene* s, int32_t n, const float* origins, const float*
     st->trace_ms += ms;
     st->trace_launches += 1;
   }
+  return JADE_OK;
+}
+
+// Development / tests (not part of jade_rt.h): hitBVH through the PACKET form of the walk (jade_trace.h; what k_light_packet
+// runs), rays taken 64 at a time in the order given.  Like jade_trace_rays, plus per-ray counts of node records and triangle tests.
+int jade_debug_packet_rays(jade_scene* s, int32_t n, const float* origins, const float* dirs, const int32_t* skip, int32_t* hit_index,
+                           float* hit_dist, float* hit_point, uint32_t* v_per_ray, uint32_t* t_per_ray) {
+  if (!s || n <= 0 || !origins || !dirs || !skip || !hit_index || !hit_dist || !hit_point || !v_per_ray || !t_per_ray) return fail(JADE_ERR_INVALID, "null argument");
+  if (s->bvh_depth > JADE_PACKET_MAX_DEPTH) return fail(JADE_ERR_UNSUPPORTED, "tree too deep for the packet form");
+  HIP_TRY(hipSetDevice(s->device));
+  const size_t N = (size_t)n;
+  DevBuf bo, bd, bs, bh, bt, bp, bv, bc;
+  HIP_TRY(upload(bo, origins, 3 * N, s->stream));
+  HIP_TRY(upload(bd, dirs, 3 * N, s->stream));
+  HIP_TRY(upload(bs, skip, N, s->stream));
+  HIP_TRY(bh.alloc(N * 4)); HIP_TRY(bt.alloc(N * 4)); HIP_TRY(bp.alloc(N * 12)); HIP_TRY(bv.alloc(N * 4)); HIP_TRY(bc.alloc(N * 4));
+  hipLaunchKernelGGL(k_packet_rays, dim3((unsigned)((N + JADE_TRACE_BLOCK - 1) / JADE_TRACE_BLOCK)), dim3(JADE_TRACE_BLOCK), 0, s->stream, s->dev, n,
+                     bo.as<float>(), bd.as<float>(), bs.as<int32_t>(), bh.as<int32_t>(), bt.as<float>(), bp.as<float>(), bv.as<uint32_t>(), bc.as<uint32_t>());
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(hit_index, bh.p, N * 4, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipMemcpyAsync(hit_dist, bt.p, N * 4, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipMemcpyAsync(hit_point, bp.p, N * 12, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipMemcpyAsync(v_per_ray, bv.p, N * 4, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipMemcpyAsync(t_per_ray, bc.p, N * 4, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
   return JADE_OK;
 }
 

@@ -968,10 +968,11 @@ static __device__ __forceinline__ void packet_pop(uint32_t stack, uint32_t sp, u
   lds_ld64(a, r, d);
   lds_ld64(a + 8u, l0, l1);
   lds_ld64(a + 16u, f0, f1);
-  ref = __builtin_amdgcn_readfirstlane(r);
-  depth = __builtin_amdgcn_readfirstlane(d);
-  lanes = (unsigned long long)__builtin_amdgcn_readfirstlane(l0) | ((unsigned long long)__builtin_amdgcn_readfirstlane(l1) << 32);
-  far = (unsigned long long)__builtin_amdgcn_readfirstlane(f0) | ((unsigned long long)__builtin_amdgcn_readfirstlane(f1) << 32);
+  // (readfirstlane returns an int: through uint32_t, or the low word sign-extends into the lanes 32-63)
+  ref = (uint32_t)__builtin_amdgcn_readfirstlane(r);
+  depth = (uint32_t)__builtin_amdgcn_readfirstlane(d);
+  lanes = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(l0) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(l1) << 32);
+  far = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(f0) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(f1) << 32);
 }
 
 // hitBVH (PathTrace.cu:795-859) for the rays of the lanes with `active`, all lanes of the wave taking part in the control
