@@ -932,15 +932,34 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_LIGHT_WAVES) void k_light(De
 // of k_light (and of shade_record<true> + k_trace): the same bits (test_result_independent_of_shade_schedule).
 // ---------------------------------------------------------------------------------------------------------------
 #ifndef JADE_PACKET_WAVES
-#define JADE_PACKET_WAVES 5
+#define JADE_PACKET_WAVES 4 /* 128 VGPRs; at 5 (96 VGPRs, 168 bytes of scratch) the kernel took 228 instead of 191 ms per step on C3 */
 #endif
 __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_PACKET_WAVES) void k_light_packet(DevScene S, PathState P, RenderConst R, const int32_t* tile_ids,
                                                                                    uint32_t target_spp, uint32_t* heavy_regions, uint32_t region_cap,
-                                                                                   uint32_t* wave_counts, DevCounters* ctr) {
+                                                                                   uint32_t* wave_counts, uint32_t* spill, DevCounters* ctr, uint32_t budget) {
   __shared__ __attribute__((aligned(16))) uint32_t lds_stack[JADE_TRACE_BLOCK / 64][8 * (JADE_PACKET_MAX_DEPTH + 1)];
+  __shared__ __attribute__((aligned(JADE_COLS_ALIGN))) uint32_t lds_cols[LW_END * JADE_TRACE_BLOCK];  // the per-lane form's columns (a packet given up)
   __shared__ uint32_t sh_ctr[JADE_TRACE_BLOCK / 64][8];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const uint32_t stack = lds_addr_of(&lds_stack[w][0]);
+  LdsStack stk;
+  stk.lds = lds_cols + threadIdx.x;
+  stk.col = lds_addr_of(stk.lds);
+  stk.spill = spill + (blockIdx.x * blockDim.x + threadIdx.x);
+  stk.stride_spill = gridDim.x * blockDim.x;
+  stk.top = nullptr;
+  stk.top_k = 0;
+#if JADE_LDS_TOP_NODES > 0
+  __shared__ float4 lds_top[4 * JADE_LDS_TOP_NODES];
+  {
+    const uint32_t k = S.top_k;
+    for (uint32_t i = threadIdx.x; i < 4u * k; i += JADE_TRACE_BLOCK) lds_top[(i & 3u) * JADE_LDS_TOP_NODES + (i >> 2)] = S.nodes[i];
+    __syncthreads();
+    stk.top = lds_top;
+    stk.top_k = k;
+  }
+#endif
+  uint32_t n_given_up = 0, n_packets = 0;
   const int npix = P.npix;
   const size_t sn = (size_t)P.sum_lanes * (size_t)P.npx;
   uint32_t vcnt = 0, tcnt = 0, n_mirror = 0;
@@ -1050,11 +1069,50 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_PACKET_WAVES) void k_light_p
         const bool exact = !(finite_f(1.0f / d.x) && finite_f(1.0f / d.y) && finite_f(1.0f / d.z)) || !finite_f(o.x) || !finite_f(o.y) || !finite_f(o.z);
         PacketBest best;
         if (go) vcnt += 1;  // the root record
-        if (S.general_walk || __ballot(go && exact) != 0ull) packet_trace<true>(S, stack, lane, go, o, d, rp.sk, vcnt, tcnt, best);
-        else packet_trace<false>(S, stack, lane, go, o, d, rp.sk, vcnt, tcnt, best);
-        if (go) {
-          rp.h = (int32_t)best.index;
-          rp.hp = best.point;
+        uint32_t pv = 0, pt = 0;  // the packet's counts: kept only if it runs to the end
+        const bool general = S.general_walk || __ballot(go && exact) != 0ull;
+        const bool whole = general ? packet_trace<true>(S, stack, lane, go, o, d, rp.sk, pv, pt, best, budget)
+                                   : packet_trace<false>(S, stack, lane, go, o, d, rp.sk, pv, pt, best, budget);
+        n_packets += 1;
+        if (whole) {
+          vcnt += pv;
+          tcnt += pt;
+          if (go) {
+            rp.h = (int32_t)best.index;
+            rp.hp = best.point;
+          }
+        } else {
+          // ---- given up (the rays fan out): the same rays per lane, every lane testing the leaves of its own ray in the order it
+          // meets them (RayState, jade_trace.h: what k_light does for all its rays)
+          n_given_up += 1;
+          RayState r;
+          bool active = go;
+          if (go) ray_begin(r, stk, S, o, d, rp.sk);
+          else ray_clear(r, stk);
+          while (__ballot(active) != 0ull) {
+            const bool cw = active && ray_can_walk(r), ct = active && ray_can_test(r);
+            const int nw = __popcll(__ballot(cw)), nt = __popcll(__ballot(ct));
+            if (JADE_COST_TRI * nw >= JADE_COST_NODE * nt) {
+              if (general) {
+#pragma nounroll
+                for (int rep = 0; rep < JADE_STEPS_PER_PICK; ++rep)
+                  if (active && ray_can_walk(r)) ray_step_node_s<true>(r, S, stk, vcnt);
+              } else {
+#pragma nounroll
+                for (int rep = 0; rep < JADE_STEPS_PER_PICK; ++rep)
+                  if (active && ray_can_walk(r)) ray_step_node_s<false>(r, S, stk, vcnt);
+              }
+            } else {
+#pragma nounroll
+              for (int rep = 0; rep < JADE_STEPS_PER_PICK; ++rep)
+                if (active && ray_can_test(r)) ray_step_tri_s(r, S, stk, tcnt);
+            }
+            if (active && ray_done(r)) active = false;
+          }
+          if (go) {
+            rp.h = ray_best_index(stk);
+            if (rp.h >= 0) rp.hp = ray_hit_point(stk);
+          }
         }
       }
       // ---- fold the result in (shade_record's part (a))
@@ -1128,6 +1186,8 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_PACKET_WAVES) void k_light_p
       if (sv) atomicAdd(&cs->nodes_inline, sv);
       if (stt) atomicAdd(&cs->tris_inline, stt);
       if (s0 + s6) atomicAdd(&cs->rays_inline, (unsigned long long)s0 + s6);
+      if (n_packets) atomicAdd(&cs->pad[0], (unsigned long long)n_packets);    // packets started / given up (JADE_LOG_PASSES)
+      if (n_given_up) atomicAdd(&cs->pad[1], (unsigned long long)n_given_up);
     }
     __syncthreads();
     if (threadIdx.x < 8) {
@@ -1152,8 +1212,8 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK) void k_packet_rays(DevScene S, in
   const bool exact = !(finite_f(1.0f / d.x) && finite_f(1.0f / d.y) && finite_f(1.0f / d.z)) || !finite_f(o.x) || !finite_f(o.y) || !finite_f(o.z);
   uint32_t vcnt = have ? 1u : 0u, tcnt = 0;
   PacketBest best;
-  if (S.general_walk || __ballot(have && exact) != 0ull) packet_trace<true>(S, lds_addr_of(&lds_stack[w][0]), lane, have, o, d, skip[k], vcnt, tcnt, best);
-  else packet_trace<false>(S, lds_addr_of(&lds_stack[w][0]), lane, have, o, d, skip[k], vcnt, tcnt, best);
+  if (S.general_walk || __ballot(have && exact) != 0ull) (void)packet_trace<true>(S, lds_addr_of(&lds_stack[w][0]), lane, have, o, d, skip[k], vcnt, tcnt, best, 0xffffffffu);
+  else (void)packet_trace<false>(S, lds_addr_of(&lds_stack[w][0]), lane, have, o, d, skip[k], vcnt, tcnt, best, 0xffffffffu);
   if (have) {
     hit[i] = (int32_t)best.index;
     dist[i] = best.dist;
@@ -1289,6 +1349,9 @@ struct DevEvent {  // an event that is destroyed on every return path
   hipError_t create() { return hipEventCreate(&e); }
 };
 
+#ifndef JADE_PACKET_BUDGET
+#define JADE_PACKET_BUDGET 48
+#endif
 // Development switches, read from the environment ONCE, at jade_scene_create (the product path reads no environment
 // variable per call).  Every one of them changes the schedule only, never a result (tests/test_gpu_parity.py).
 struct Tunables {
@@ -1303,6 +1366,7 @@ struct Tunables {
   int trace_blocks_per_cu = 0;  // JADE_TRACE_BLOCKS_PER_CU: occupancy sweeps
   bool force_rccl = false;    // JADE_FORCE_RCCL=1 (tests): the RCCL path for a single share too
   bool light_packet = true;   // JADE_LIGHT_PACKET=0: the fused first pass walks its rays per lane (k_light) instead of as packets
+  int packet_budget = JADE_PACKET_BUDGET;  // JADE_PACKET_BUDGET: records a packet may read before it is given up and walked per lane
   void read() {
     auto flag0 = [](const char* n) { const char* e = getenv(n); return e && atoi(e) == 0; };
     auto flag1 = [](const char* n) { const char* e = getenv(n); return e && atoi(e) > 0; };
@@ -1317,6 +1381,7 @@ struct Tunables {
     if (const char* e = getenv("JADE_TRACE_BLOCKS_PER_CU")) trace_blocks_per_cu = atoi(e);
     force_rccl = getenv("JADE_FORCE_RCCL") != nullptr;
     light_packet = !flag0("JADE_LIGHT_PACKET");
+    if (const char* e = getenv("JADE_PACKET_BUDGET")) packet_budget = atoi(e);
   }
 };
 
@@ -1745,6 +1810,7 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&pk_cu, k_light_packet, JADE_TRACE_BLOCK, 0);
     if (pk_cu < 1) pk_cu = 1;
     if (pk_cu > 8) pk_cu = 8;
+    if (pk_cu > per_cu) pk_cu = per_cu;  // the stack spill area is sized for the k_trace grid
     s->packet_blocks = prop.multiProcessorCount * pk_cu;
   }
   if (s->tun.log_passes) fprintf(stderr, "[jade] first pass: k_light %d blocks, k_light_packet %d blocks (tree depth %d)\n", s->light_blocks, s->packet_blocks, depth);
@@ -2063,7 +2129,8 @@ static int run_passes(jade_scene* s, int64_t from_spp, uint32_t target_spp, bool
           return fail(JADE_ERR_DEVICE, "hand-over regions do not fit (internal sizing error)");
         if (packet)
           hipLaunchKernelGGL(k_light_packet, dim3(lb), dim3(JADE_TRACE_BLOCK), 0, s->stream, s->dev, s->ps, s->rc, s->b_tiles.as<int32_t>(), target_spp,
-                             s->b_active[0].as<uint32_t>(), region_cap, s->b_wavecnt.as<uint32_t>(), s->b_ctr.as<DevCounters>());
+                             s->b_active[0].as<uint32_t>(), region_cap, s->b_wavecnt.as<uint32_t>(), s->b_spill.as<uint32_t>(), s->b_ctr.as<DevCounters>(),
+                             (uint32_t)s->tun.packet_budget);
         else
           hipLaunchKernelGGL(k_light, dim3(lb), dim3(JADE_TRACE_BLOCK), 0, s->stream, s->dev, s->ps, s->rc, s->b_tiles.as<int32_t>(), target_spp,
                              s->b_active[0].as<uint32_t>(), region_cap, s->b_wavecnt.as<uint32_t>(), s->b_spill.as<uint32_t>(),
@@ -2211,6 +2278,9 @@ static int advance(jade_scene* s, int64_t from0, bool may_carry, jade_stats* st)
     st->tris_tested += c.tris_tested;
     st->shaded_hits += c.shaded_hits;
     st->samples += c.samples;
+    if (s->tun.log_passes && c.pad[0])
+      fprintf(stderr, "[jade] first pass: %llu packets, %llu given up and walked per lane (%.2f %%)\n", (unsigned long long)c.pad[0],
+              (unsigned long long)c.pad[1], 100.0 * (double)c.pad[1] / (double)c.pad[0]);
     st->kernel_ms += ms;
     st->trace_ms += trace_ms;
     st->trace_launches += launches;

@@ -979,9 +979,13 @@ static __device__ __forceinline__ void packet_pop(uint32_t stack, uint32_t sp, u
 // flow.  o, d, skip: this lane's ray; vcnt / tcnt: this lane's counts of child records visited and triangles tested (the
 // root record is the caller's, as with ray_begin).  stack: LDS byte address of JADE_PACKET_MAX_DEPTH + 1 entries of 32 bytes
 // for this wave.  best: this lane's result (index 0xffffffff = miss).
+// budget: node and pair records the packet may read; past it the walk is given up and false returned (vcnt / tcnt / best
+// then hold a partial walk: the caller discards them and walks these rays per lane).  A packet pays one record per node of
+// the UNION of its rays' walks: rays that fan out into a finely tessellated object (64 lanes, 64 leaves, each reached by one
+// lane) cost it 64 walks of one lane each, every record a dependent scalar load.
 template <bool GENERAL>
-static __device__ __forceinline__ void packet_trace(const DevScene& S, uint32_t stack, int lane, bool active, jvec3 o, jvec3 d, int32_t skip,
-                                                    uint32_t& vcnt, uint32_t& tcnt, PacketBest& best) {
+static __device__ __forceinline__ bool packet_trace(const DevScene& S, uint32_t stack, int lane, bool active, jvec3 o, jvec3 d, int32_t skip,
+                                                    uint32_t& vcnt, uint32_t& tcnt, PacketBest& best, uint32_t budget) {
   RayOD od;
   const jvec3 inv = jv(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
   const jvec3 dn = jv_normalize(d);
@@ -997,8 +1001,10 @@ static __device__ __forceinline__ void packet_trace(const DevScene& S, uint32_t 
   const unsigned long long me = 1ull << lane;
   uint32_t cur = S.root_ref, depth = 0, sp = 0;
   unsigned long long lanes = __ballot(active), far = 0ull;
-  if (lanes == 0ull) return;
+  if (lanes == 0ull) return true;
+  uint32_t records = 0;
   for (;;) {
+    if (records > budget) return false;
     const bool in = (lanes & me) != 0ull;
     // this node's bit of the path: set for the lanes it is the far child for
     const unsigned long long bit = 1ull << (63u - depth);
@@ -1007,6 +1013,7 @@ static __device__ __forceinline__ void packet_trace(const DevScene& S, uint32_t 
       // ---- a leaf: its pair records, one after the other, for the lanes that entered it (hitArray, :776-792)
       const unsigned long long key = path & ~(bit - 1ull);  // (levels below this leaf hold bits of paths walked before)
       uint32_t off = cur & 0x7ffffff0u;
+      records += cur & 15u;
       for (uint32_t n = cur & 15u; n != 0u; --n, off += 80u) {
         jade_const_f4* t = as_const_f4(S.tverts, off);
         PairRec rec;
@@ -1037,6 +1044,7 @@ static __device__ __forceinline__ void packet_trace(const DevScene& S, uint32_t 
       }
     } else {
       // ---- an internal node: both children's boxes from its record (hitAABB x 2, :825-832)
+      records += 1u;
       jade_const_f4* nd = as_const_f4(S.nodes, cur * 64u);
       const float4 a = ld_const_f4(nd), b = ld_const_f4(nd + 1), c = ld_const_f4(nd + 2), r4 = ld_const_f4(nd + 3);
       const uint32_t left = jade_f2u(r4.x), right = jade_f2u(r4.y);
@@ -1079,4 +1087,5 @@ static __device__ __forceinline__ void packet_trace(const DevScene& S, uint32_t 
     sp -= 1u;
     packet_pop(stack, sp, cur, depth, lanes, far);
   }
+  return true;
 }
