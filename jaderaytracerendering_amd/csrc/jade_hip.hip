@@ -936,29 +936,11 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_LIGHT_WAVES) void k_light(De
 #endif
 __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_PACKET_WAVES) void k_light_packet(DevScene S, PathState P, RenderConst R, const int32_t* tile_ids,
                                                                                    uint32_t target_spp, uint32_t* heavy_regions, uint32_t region_cap,
-                                                                                   uint32_t* wave_counts, uint32_t* spill, DevCounters* ctr, uint32_t budget) {
+                                                                                   uint32_t* wave_counts, DevCounters* ctr, uint32_t budget) {
   __shared__ __attribute__((aligned(16))) uint32_t lds_stack[JADE_TRACE_BLOCK / 64][8 * (JADE_PACKET_MAX_DEPTH + 1)];
-  __shared__ __attribute__((aligned(JADE_COLS_ALIGN))) uint32_t lds_cols[LW_END * JADE_TRACE_BLOCK];  // the per-lane form's columns (a packet given up)
   __shared__ uint32_t sh_ctr[JADE_TRACE_BLOCK / 64][8];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const uint32_t stack = lds_addr_of(&lds_stack[w][0]);
-  LdsStack stk;
-  stk.lds = lds_cols + threadIdx.x;
-  stk.col = lds_addr_of(stk.lds);
-  stk.spill = spill + (blockIdx.x * blockDim.x + threadIdx.x);
-  stk.stride_spill = gridDim.x * blockDim.x;
-  stk.top = nullptr;
-  stk.top_k = 0;
-#if JADE_LDS_TOP_NODES > 0
-  __shared__ float4 lds_top[4 * JADE_LDS_TOP_NODES];
-  {
-    const uint32_t k = S.top_k;
-    for (uint32_t i = threadIdx.x; i < 4u * k; i += JADE_TRACE_BLOCK) lds_top[(i & 3u) * JADE_LDS_TOP_NODES + (i >> 2)] = S.nodes[i];
-    __syncthreads();
-    stk.top = lds_top;
-    stk.top_k = k;
-  }
-#endif
   uint32_t n_given_up = 0, n_packets = 0;
   const int npix = P.npix;
   const size_t sn = (size_t)P.sum_lanes * (size_t)P.npx;
@@ -1001,6 +983,7 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_PACKET_WAVES) void k_light_p
     rp.sk = -1;
     bool finished = false;
     jvec3 color = jv(0, 0, 0), l_final = jv(0, 0, 0);
+    uint32_t rng_vertex = 0;
     for (;;) {
       // ---- every lane without a ray advances until it has one (camera or mirror), is out of samples, or parks
       if (mine && st != ST_PRIMARY && st != ST_MIRROR) {
@@ -1020,6 +1003,7 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_PACKET_WAVES) void k_light_p
               mine = false;
               break;
             }
+            rng_vertex = c.rng;  // (a mirror packet that is given up goes back to this vertex)
             if (begin_bounce_lean(S, rp, c, &l_final)) {  // the mirror ray is in rp
               n_mirror += 1;
               st = ST_MIRROR;
@@ -1064,56 +1048,44 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_PACKET_WAVES) void k_light_p
       // ---- one packet of ONE kind of ray, the kind more lanes hold (a lane with the other kind waits: a wave whose pixels
       // all see the floor alternates camera packets and mirror packets of 64 rays each)
       const bool go = __popcll(mc) >= __popcll(mm) ? cam : mir;
+      bool whole = true;
       {
         const jvec3 o = rp.o, d = rp.d;
         const bool exact = !(finite_f(1.0f / d.x) && finite_f(1.0f / d.y) && finite_f(1.0f / d.z)) || !finite_f(o.x) || !finite_f(o.y) || !finite_f(o.z);
         PacketBest best;
-        if (go) vcnt += 1;  // the root record
         uint32_t pv = 0, pt = 0;  // the packet's counts: kept only if it runs to the end
         const bool general = S.general_walk || __ballot(go && exact) != 0ull;
-        const bool whole = general ? packet_trace<true>(S, stack, lane, go, o, d, rp.sk, pv, pt, best, budget)
-                                   : packet_trace<false>(S, stack, lane, go, o, d, rp.sk, pv, pt, best, budget);
+        whole = general ? packet_trace<true>(S, stack, lane, go, o, d, rp.sk, pv, pt, best, budget)
+                        : packet_trace<false>(S, stack, lane, go, o, d, rp.sk, pv, pt, best, budget);
         n_packets += 1;
         if (whole) {
-          vcnt += pv;
-          tcnt += pt;
           if (go) {
+            vcnt += pv + 1u;  // + the root record
+            tcnt += pt;
             rp.h = (int32_t)best.index;
             rp.hp = best.point;
           }
-        } else {
-          // ---- given up (the rays fan out): the same rays per lane, every lane testing the leaves of its own ray in the order it
-          // meets them (RayState, jade_trace.h: what k_light does for all its rays)
-          n_given_up += 1;
-          RayState r;
-          bool active = go;
-          if (go) ray_begin(r, stk, S, o, d, rp.sk);
-          else ray_clear(r, stk);
-          while (__ballot(active) != 0ull) {
-            const bool cw = active && ray_can_walk(r), ct = active && ray_can_test(r);
-            const int nw = __popcll(__ballot(cw)), nt = __popcll(__ballot(ct));
-            if (JADE_COST_TRI * nw >= JADE_COST_NODE * nt) {
-              if (general) {
-#pragma nounroll
-                for (int rep = 0; rep < JADE_STEPS_PER_PICK; ++rep)
-                  if (active && ray_can_walk(r)) ray_step_node_s<true>(r, S, stk, vcnt);
-              } else {
-#pragma nounroll
-                for (int rep = 0; rep < JADE_STEPS_PER_PICK; ++rep)
-                  if (active && ray_can_walk(r)) ray_step_node_s<false>(r, S, stk, vcnt);
-              }
-            } else {
-#pragma nounroll
-              for (int rep = 0; rep < JADE_STEPS_PER_PICK; ++rep)
-                if (active && ray_can_test(r)) ray_step_tri_s(r, S, stk, tcnt);
-            }
-            if (active && ray_done(r)) active = false;
+        } else if (go) {
+          // ---- given up (the rays fan out, e.g. into the statue): these lanes go back to where the ray came from and hand
+          // their records to the wavefront passes, whose per-lane walk is the right tool for such rays - a camera ray back to
+          // "sample not started" (its stream is seeded per sample), a mirror ray back to the vertex it left, with the random
+          // state it had there.  k_shade continues from either (shade_record); nothing of the partial walk is kept.
+          if (st == ST_PRIMARY) {
+            c.c_primary -= 1;
+            st = ST_IDLE;
+          } else {
+            c.rng = rng_vertex;
+            c.c_shaded -= 1;
+            n_mirror -= 1;
+            st = ST_VERTEX;
           }
-          if (go) {
-            rp.h = ray_best_index(stk);
-            if (rp.h >= 0) rp.hp = ray_hit_point(stk);
-          }
+          defer = true;
+          mine = false;
         }
+      }
+      if (!whole) {
+        n_given_up += 1;
+        continue;
       }
       // ---- fold the result in (shade_record's part (a))
       if (go) {
@@ -1810,7 +1782,6 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&pk_cu, k_light_packet, JADE_TRACE_BLOCK, 0);
     if (pk_cu < 1) pk_cu = 1;
     if (pk_cu > 8) pk_cu = 8;
-    if (pk_cu > per_cu) pk_cu = per_cu;  // the stack spill area is sized for the k_trace grid
     s->packet_blocks = prop.multiProcessorCount * pk_cu;
   }
   if (s->tun.log_passes) fprintf(stderr, "[jade] first pass: k_light %d blocks, k_light_packet %d blocks (tree depth %d)\n", s->light_blocks, s->packet_blocks, depth);
@@ -2129,7 +2100,7 @@ static int run_passes(jade_scene* s, int64_t from_spp, uint32_t target_spp, bool
           return fail(JADE_ERR_DEVICE, "hand-over regions do not fit (internal sizing error)");
         if (packet)
           hipLaunchKernelGGL(k_light_packet, dim3(lb), dim3(JADE_TRACE_BLOCK), 0, s->stream, s->dev, s->ps, s->rc, s->b_tiles.as<int32_t>(), target_spp,
-                             s->b_active[0].as<uint32_t>(), region_cap, s->b_wavecnt.as<uint32_t>(), s->b_spill.as<uint32_t>(), s->b_ctr.as<DevCounters>(),
+                             s->b_active[0].as<uint32_t>(), region_cap, s->b_wavecnt.as<uint32_t>(), s->b_ctr.as<DevCounters>(),
                              (uint32_t)s->tun.packet_budget);
         else
           hipLaunchKernelGGL(k_light, dim3(lb), dim3(JADE_TRACE_BLOCK), 0, s->stream, s->dev, s->ps, s->rc, s->b_tiles.as<int32_t>(), target_spp,
