@@ -1322,7 +1322,7 @@ struct DevEvent {  // an event that is destroyed on every return path
 };
 
 #ifndef JADE_PACKET_BUDGET
-#define JADE_PACKET_BUDGET 48
+#define JADE_PACKET_BUDGET 32 /* C3: k_light 153 / 159 / 167 / 181 ms per step at 16 / 32 / 64 / 128, and the step as a whole fastest at 32 (a lower budget hands more samples to the wavefront passes); C5: 32 / 33 / 36 ms at 16 / 32 / 64 */
 #endif
 // Development switches, read from the environment ONCE, at jade_scene_create (the product path reads no environment
 // variable per call).  Every one of them changes the schedule only, never a result (tests/test_gpu_parity.py).
@@ -2596,7 +2596,7 @@ int jade_trace_rays(jade_scene* s, int32_t n, const float* origins, const float*
 // Development / tests (not part of jade_rt.h): hitBVH through the PACKET form of the walk (jade_trace.h; what k_light_packet
 // runs), rays taken 64 at a time in the order given.  Like jade_trace_rays, plus per-ray counts of node records and triangle tests.
 int jade_debug_packet_rays(jade_scene* s, int32_t n, const float* origins, const float* dirs, const int32_t* skip, int32_t* hit_index,
-                           float* hit_dist, float* hit_point, uint32_t* v_per_ray, uint32_t* t_per_ray) {
+                           float* hit_dist, float* hit_point, uint32_t* v_per_ray, uint32_t* t_per_ray, double* kernel_ms /* nullable */) {
   if (!s || n <= 0 || !origins || !dirs || !skip || !hit_index || !hit_dist || !hit_point || !v_per_ray || !t_per_ray) return fail(JADE_ERR_INVALID, "null argument");
   if (s->bvh_depth > JADE_PACKET_MAX_DEPTH) return fail(JADE_ERR_UNSUPPORTED, "tree too deep for the packet form");
   HIP_TRY(hipSetDevice(s->device));
@@ -2606,15 +2606,25 @@ int jade_debug_packet_rays(jade_scene* s, int32_t n, const float* origins, const
   HIP_TRY(upload(bd, dirs, 3 * N, s->stream));
   HIP_TRY(upload(bs, skip, N, s->stream));
   HIP_TRY(bh.alloc(N * 4)); HIP_TRY(bt.alloc(N * 4)); HIP_TRY(bp.alloc(N * 12)); HIP_TRY(bv.alloc(N * 4)); HIP_TRY(bc.alloc(N * 4));
+  DevEvent e0, e1;
+  HIP_TRY(e0.create());
+  HIP_TRY(e1.create());
+  HIP_TRY(hipEventRecord(e0.e, s->stream));
   hipLaunchKernelGGL(k_packet_rays, dim3((unsigned)((N + JADE_TRACE_BLOCK - 1) / JADE_TRACE_BLOCK)), dim3(JADE_TRACE_BLOCK), 0, s->stream, s->dev, n,
                      bo.as<float>(), bd.as<float>(), bs.as<int32_t>(), bh.as<int32_t>(), bt.as<float>(), bp.as<float>(), bv.as<uint32_t>(), bc.as<uint32_t>());
   HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(e1.e, s->stream));
   HIP_TRY(hipMemcpyAsync(hit_index, bh.p, N * 4, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipMemcpyAsync(hit_dist, bt.p, N * 4, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipMemcpyAsync(hit_point, bp.p, N * 12, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipMemcpyAsync(v_per_ray, bv.p, N * 4, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipMemcpyAsync(t_per_ray, bc.p, N * 4, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  if (kernel_ms) {
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0.e, e1.e));
+    *kernel_ms = ms;
+  }
   return JADE_OK;
 }
 

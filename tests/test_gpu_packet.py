@@ -18,12 +18,12 @@ pytestmark = pytest.mark.gpu
 def _packet_rays(hip, sc, o, d, skip):
     fn = hip.lib.jade_debug_packet_rays  # development export of libjade_hip.so (not part of jade_rt.h)
     fn.restype = C.c_int
-    fn.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 8
+    fn.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 9
     n = len(o)
     hit, dist, pt = np.zeros(n, np.int32), np.zeros(n, np.float32), np.zeros((n, 3), np.float32)
     v, t = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
     hip.check(fn(sc._h, n, o.ctypes.data, d.ctypes.data, skip.ctypes.data, hit.ctypes.data, dist.ctypes.data, pt.ctypes.data,
-                 v.ctypes.data, t.ctypes.data))
+                 v.ctypes.data, t.ctypes.data, None))
     return hit, dist, pt, v, t
 
 
