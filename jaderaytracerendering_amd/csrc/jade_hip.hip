@@ -33,6 +33,8 @@
 #include <string>
 #include <vector>
 
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include "jade_device.h"
 #include "jade_shade.h"
 #include "jade_trace.h"
@@ -484,6 +486,32 @@ __global__ __launch_bounds__(JADE_LEAN_BLOCK) void k_shade_lean(DevScene S, Path
   shade_tail<true, JADE_LEAN_BLOCK / 64>(P, p, st, c, defer, nullptr, heavy_out, queue, qc, ctr);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Ray-queue ordering (north_star: "ray compaction/sort via wave-ballot/prefix-sum primitives"), OPT-IN (JADE_SORT=1).  Which ray
+// sits beside which in the queue is free to choose: every result is written back to the ray's own slot, so no bit of any
+// result depends on the order.  A ray's key: the kind of ray (shadow ray towards emitter i / environment ray / indirect ray /
+// single-ray stage), then the triangle it leaves - its index in BVH order is a place on the tree's own space-filling curve -
+// then the octant it heads into; rocPRIM sorts (key, queue entry) pairs, so the host has to know the queue's length: passes are
+// host-followed while this is on.  Measured (profiles/r03_ray_ordering.json, r03_packet_shadow_probe.json): on C3, whose tree
+// sits in the L2, a wave whose rays read the same lines is 2.6 % faster and the sort costs 9 %; it is meant for scenes whose
+// geometry does not fit the L2 (C5: k_trace is bound by the rate of 64-B sector misses there).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void k_ray_keys(PathState P, const uint32_t* queue, uint32_t n, uint32_t* keys, int n_emit, uint32_t tri_bits) {  // tri_bits: bits of the largest triangle index
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t e = queue[i];
+  const uint32_t p = e / (uint32_t)P.nslots, k = e - p * (uint32_t)P.nslots;
+  const uint32_t st = P.hdr[p].z & 255u;
+  const float4 og = P.orgs[p];
+  const int32_t skip = __float_as_int(og.w);
+  const float4 dv = P.slot[(size_t)e * 2];
+  uint32_t cls = 7u;  // single-ray stages (mirror, refraction, camera)
+  if (st == ST_DIFFUSE || st == ST_BSSRDF) cls = (int)k < n_emit ? (k < 5u ? k : 4u) : ((int)k == n_emit ? 5u : 6u);
+  const uint32_t tri = skip < 0 ? 0u : ((uint32_t)skip & ((1u << tri_bits) - 1u));
+  const uint32_t oct = (dv.x < 0.0f ? 1u : 0u) | (dv.y < 0.0f ? 2u : 0u) | (dv.z < 0.0f ? 4u : 0u);
+  keys[i] = (cls << 29) | (((tri << 3) | oct) << (26u - tri_bits));  // left-aligned: kind, triangle, octant
+}
+
 #define JADE_CTL_RING 32 /* QueueCtl records: entry 0 for passes the host follows one by one, all of them for a batch of passes */
 #ifndef JADE_TRACE_NT
 #define JADE_TRACE_NT 1 /* k_trace reads and writes the ray records with non-temporal hints */
@@ -525,6 +553,12 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
   stk.top = nullptr;
   stk.top_k = 0;
   if (qc->count == 0) return;  // (a pass of a batch behind the one that ended the step: nothing was queued)
+  // The grid is sized for a full queue (in a batch of passes the host does not know the length); a short queue keeps one
+  // block per JADE_TRACE_BLOCK rays and the others leave before they stage anything: the thin passes at the end of a render
+  // (under 10 k rays: 40 blocks instead of 1280) were mostly 1280 copies of the tree top into LDS.  The blocks that stay claim
+  // chunks until the queue is empty, as ever.
+  if ((unsigned long long)blockIdx.x * JADE_TRACE_BLOCK >= (unsigned long long)qc->count) return;
+#if JADE_TRACE_TOP_NODES > 0 && JADE_LDS_TOP_NODES > 0
   __shared__ float4 lds_top[4 * JADE_TRACE_TOP_NODES];
   {  // stage the top of the tree: record i's j-th 16 bytes -> plane j, entry i (coalesced reads of S.nodes)
     const uint32_t k = S.top_k < JADE_TRACE_TOP_NODES ? S.top_k : JADE_TRACE_TOP_NODES;
@@ -533,6 +567,7 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
     stk.top = lds_top;
     stk.top_k = k;
   }
+#endif
   const uint32_t n = qc->count;
   if (chunk == 0) {  // batched passes: the host has not seen the queue length (trace_chunk's rule, on the device)
     const uint32_t waves = gridDim.x * (JADE_TRACE_BLOCK / 64);
@@ -1337,6 +1372,8 @@ struct Tunables {
   int records_per_pixel = 0;  // JADE_RECORDS_PER_PIXEL: test hook, results must not depend on it
   int trace_blocks_per_cu = 0;  // JADE_TRACE_BLOCKS_PER_CU: occupancy sweeps
   bool force_rccl = false;    // JADE_FORCE_RCCL=1 (tests): the RCCL path for a single share too
+  int sort_mode = 0;          // JADE_SORT=1: order the ray queue by (kind, source triangle, octant) before every k_trace launch (host-followed passes)
+  uint32_t sort_min = 65536;  // JADE_SORT_MIN: queues shorter than this are traced as they are
   bool light_packet = true;   // JADE_LIGHT_PACKET=0: the fused first pass walks its rays per lane (k_light) instead of as packets
   int packet_budget = JADE_PACKET_BUDGET;  // JADE_PACKET_BUDGET: records a packet may read before it is given up and walked per lane
   void read() {
@@ -1353,6 +1390,9 @@ struct Tunables {
     if (const char* e = getenv("JADE_TRACE_BLOCKS_PER_CU")) trace_blocks_per_cu = atoi(e);
     force_rccl = getenv("JADE_FORCE_RCCL") != nullptr;
     light_packet = !flag0("JADE_LIGHT_PACKET");
+    if (const char* e = getenv("JADE_SORT")) sort_mode = atoi(e);
+    if (const char* e = getenv("JADE_SORT_MIN")) sort_min = (uint32_t)atoi(e);
+    if (sort_mode > 0) batching = false;  // rocPRIM wants the queue's length on the host
     if (const char* e = getenv("JADE_PACKET_BUDGET")) packet_budget = atoi(e);
   }
 };
@@ -1370,6 +1410,9 @@ struct jade_scene {
   jade_render_params rp{};
   RenderConst rc{};
   PathState ps{};
+  DevBuf b_sortkey, b_sortkey2, b_sortq, b_sorttmp;  // JADE_SORT: keys in / out, the ordered queue, rocPRIM's temporary storage
+  size_t sort_cap = 0, sort_tmp_bytes = 0;
+  double sort_ms = 0;
   DevBuf b_state, b_sum, b_tiles, b_queue, b_active[2], b_ctl, b_ctr, b_spill, b_out_rgb, b_out_bgr, b_wavecnt;
   std::vector<int32_t> tile_ids;
   int trace_blocks = 0;
@@ -1830,6 +1873,18 @@ static int setup_state(jade_scene* s, int npx, int rpp, int nslots, int sum_lane
   HIP_TRY(s->b_active[0].alloc((N + first_pass_blocks * JADE_TRACE_BLOCK + 64) * 4));
   HIP_TRY(s->b_active[1].alloc(N * 4));
   HIP_TRY(s->b_wavecnt.alloc((size_t)2 * first_pass_blocks * (JADE_TRACE_BLOCK / 64) * 4));
+  s->sort_cap = 0;
+  if (s->tun.sort_mode > 0) {
+    const size_t cap = std::min<size_t>(K * N, (size_t)1 << 28);
+    size_t tmp = 0;
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, cap, 0u, 32u, s->stream));
+    HIP_TRY(s->b_sortkey.alloc(cap * 4));
+    HIP_TRY(s->b_sortkey2.alloc(cap * 4));
+    HIP_TRY(s->b_sortq.alloc(cap * 4));
+    HIP_TRY(s->b_sorttmp.alloc(tmp));
+    s->sort_tmp_bytes = tmp;
+    s->sort_cap = cap;
+  }
   if (!s->b_spill.p)
     HIP_TRY(s->b_spill.alloc((size_t)(JADE_BVH_STACK_CAPACITY - JADE_LDS_STACK) * s->trace_blocks * JADE_TRACE_BLOCK * 4));
   return JADE_OK;
@@ -2161,9 +2216,21 @@ static int run_passes(jade_scene* s, int64_t from_spp, uint32_t target_spp, bool
     }
     n_active = host_ctl[1];
     if (host_ctl[0] == 0) break;
-    HIP_TRY(hipEventRecord(ta, s->stream));
+    const uint32_t* trace_queue = s->b_queue.as<uint32_t>();
+    HIP_TRY(hipEventRecord(ta, s->stream));  // (the ordering counts as trace time)
+    if (s->tun.sort_mode > 0 && host_ctl[0] >= s->tun.sort_min && host_ctl[0] <= s->sort_cap) {
+      const uint32_t n = host_ctl[0];
+      uint32_t tri_bits = 1;
+      while (tri_bits < 23 && ((uint32_t)(s->dev.n_tris - 1) >> tri_bits)) ++tri_bits;
+      hipLaunchKernelGGL(k_ray_keys, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->ps, s->b_queue.as<uint32_t>(), n, s->b_sortkey.as<uint32_t>(),
+                         s->n_emit, tri_bits);
+      size_t tmp = s->sort_tmp_bytes;
+      HIP_TRY(rocprim::radix_sort_pairs(s->b_sorttmp.p, tmp, s->b_sortkey.as<uint32_t>(), s->b_sortkey2.as<uint32_t>(), s->b_queue.as<uint32_t>(),
+                                        s->b_sortq.as<uint32_t>(), (size_t)n, 0u, 32u, s->stream));
+      trace_queue = s->b_sortq.as<uint32_t>();
+    }
     hipLaunchKernelGGL(k_trace, dim3((unsigned)s->trace_blocks), dim3(JADE_TRACE_BLOCK), 0, s->stream, s->dev, s->ps,
-                       s->b_queue.as<uint32_t>(), qc, s->b_spill.as<uint32_t>(), s->b_ctr.as<DevCounters>(),
+                       trace_queue, qc, s->b_spill.as<uint32_t>(), s->b_ctr.as<DevCounters>(),
                        trace_chunk(s, host_ctl[0]));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(tb, s->stream));
@@ -2289,7 +2356,7 @@ int jade_render_query(jade_scene* s, int what, int64_t* value) {
     case JADE_Q_RECORDS_PER_PIXEL: *value = s->ps.npix ? s->ps.rpp : 0; return JADE_OK;
     case JADE_Q_STATE_BYTES:
       *value = s->ps.npix ? (int64_t)(s->b_state.bytes + s->b_sum.bytes + s->b_queue.bytes + s->b_active[0].bytes + s->b_active[1].bytes +
-                                      s->b_wavecnt.bytes + s->b_spill.bytes)
+                                      s->b_wavecnt.bytes + s->b_spill.bytes + s->b_sortkey.bytes + s->b_sortkey2.bytes + s->b_sortq.bytes + s->b_sorttmp.bytes)
                           : 0;
       return JADE_OK;
     case JADE_Q_SUM_LANES: *value = s->ps.npix ? s->ps.sum_lanes : 0; return JADE_OK;
