@@ -1356,6 +1356,9 @@ struct DevEvent {  // an event that is destroyed on every return path
   hipError_t create() { return hipEventCreate(&e); }
 };
 
+#ifndef JADE_SORT_GEOMETRY_BYTES
+#define JADE_SORT_GEOMETRY_BYTES ((size_t)16 << 20) /* node + pair records above which the ray queue is ordered by default: four XCD L2s' worth */
+#endif
 #ifndef JADE_PACKET_BUDGET
 #define JADE_PACKET_BUDGET 32 /* C3: k_light 153 / 159 / 167 / 181 ms per step at 16 / 32 / 64 / 128, and the step as a whole fastest at 32 (a lower budget hands more samples to the wavefront passes); C5: 32 / 33 / 36 ms at 16 / 32 / 64 */
 #endif
@@ -1372,7 +1375,8 @@ struct Tunables {
   int records_per_pixel = 0;  // JADE_RECORDS_PER_PIXEL: test hook, results must not depend on it
   int trace_blocks_per_cu = 0;  // JADE_TRACE_BLOCKS_PER_CU: occupancy sweeps
   bool force_rccl = false;    // JADE_FORCE_RCCL=1 (tests): the RCCL path for a single share too
-  int sort_mode = 0;          // JADE_SORT=1: order the ray queue by (kind, source triangle, octant) before every k_trace launch (host-followed passes)
+  int sort_mode = -1;         // JADE_SORT: order the ray queue by (kind, source triangle, octant) before every k_trace launch (host-followed
+                              // passes): 1 always, 0 never, unset = when the traversal's records do not fit the L2 (jade_scene.sort_rays)
   uint32_t sort_min = 65536;  // JADE_SORT_MIN: queues shorter than this are traced as they are
   bool light_packet = true;   // JADE_LIGHT_PACKET=0: the fused first pass walks its rays per lane (k_light) instead of as packets
   int packet_budget = JADE_PACKET_BUDGET;  // JADE_PACKET_BUDGET: records a packet may read before it is given up and walked per lane
@@ -1390,9 +1394,8 @@ struct Tunables {
     if (const char* e = getenv("JADE_TRACE_BLOCKS_PER_CU")) trace_blocks_per_cu = atoi(e);
     force_rccl = getenv("JADE_FORCE_RCCL") != nullptr;
     light_packet = !flag0("JADE_LIGHT_PACKET");
-    if (const char* e = getenv("JADE_SORT")) sort_mode = atoi(e);
+    if (const char* e = getenv("JADE_SORT")) sort_mode = atoi(e) > 0 ? 1 : 0;
     if (const char* e = getenv("JADE_SORT_MIN")) sort_min = (uint32_t)atoi(e);
-    if (sort_mode > 0) batching = false;  // rocPRIM wants the queue's length on the host
     if (const char* e = getenv("JADE_PACKET_BUDGET")) packet_budget = atoi(e);
   }
 };
@@ -1405,6 +1408,7 @@ struct jade_scene {
   DevBuf b_nodes, b_tverts, b_tris, b_emit, b_mapping, b_prefix, b_segs, b_env, b_guide, b_guide_obj;
   int n_emit = 0;
   int bvh_depth = 0;
+  bool sort_rays = false;     // the ray queue is ordered before every k_trace launch (Tunables.sort_mode; then passes are host-followed)
   // render state
   bool have_rp = false;
   jade_render_params rp{};
@@ -1790,6 +1794,12 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
   s->dev.root_ref = ref_of(1);
   s->dev.top_k = (uint32_t)std::min(n_internal, (int)JADE_LDS_TOP_NODES);
   s->dev.general_walk = missing_child ? 1u : 0u;
+  // Ray ordering pays when the traversal's records do not fit the XCDs' L2s (C5: 55 MB, k_trace bound by the rate of 64-B sector
+  // misses: 4 235 -> 5 275 Mray/s); on a tree that does (C3: 3.8 MB) it costs more than it gives
+  {
+    const size_t geometry_bytes = nodes.size() * sizeof(float4) + tverts.size() * sizeof(float4);
+    s->sort_rays = s->tun.sort_mode < 0 ? geometry_bytes > JADE_SORT_GEOMETRY_BYTES : s->tun.sort_mode > 0;
+  }
 
   // the arithmetic contract of jade_fpmath.h, checked on the device once
   hipLaunchKernelGGL(k_selftest, dim3(1), dim3(1), 0, s->stream, s->b_ctl.as<QueueCtl>(), 1.0f);
@@ -1874,7 +1884,7 @@ static int setup_state(jade_scene* s, int npx, int rpp, int nslots, int sum_lane
   HIP_TRY(s->b_active[1].alloc(N * 4));
   HIP_TRY(s->b_wavecnt.alloc((size_t)2 * first_pass_blocks * (JADE_TRACE_BLOCK / 64) * 4));
   s->sort_cap = 0;
-  if (s->tun.sort_mode > 0) {
+  if (s->sort_rays) {
     const size_t cap = std::min<size_t>(K * N, (size_t)1 << 28);
     size_t tmp = 0;
     HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, cap, 0u, 32u, s->stream));
@@ -2039,7 +2049,7 @@ static int run_passes(jade_scene* s, int64_t from_spp, uint32_t target_spp, bool
                          (carry_frac > 0 && (double)act < carry_frac * (double)n_armed));
   };
   // JADE_BATCH=0: the host follows every pass (the schedule before batching existed)
-  const bool batching = s->tun.batching;
+  const bool batching = s->tun.batching && !s->sort_rays;  // (rocPRIM wants the queue's length on the host)
   bool closed_by_batch = false;  // the wait at the end of a batch was also the wait for the end of the step
   while (n_active) {
     const bool lean_mode = split_ok && (uint64_t)n_active * 4 >= (uint64_t)npix;
@@ -2218,7 +2228,7 @@ static int run_passes(jade_scene* s, int64_t from_spp, uint32_t target_spp, bool
     if (host_ctl[0] == 0) break;
     const uint32_t* trace_queue = s->b_queue.as<uint32_t>();
     HIP_TRY(hipEventRecord(ta, s->stream));  // (the ordering counts as trace time)
-    if (s->tun.sort_mode > 0 && host_ctl[0] >= s->tun.sort_min && host_ctl[0] <= s->sort_cap) {
+    if (s->sort_rays && host_ctl[0] >= s->tun.sort_min && host_ctl[0] <= s->sort_cap) {
       const uint32_t n = host_ctl[0];
       uint32_t tri_bits = 1;
       while (tri_bits < 23 && ((uint32_t)(s->dev.n_tris - 1) >> tri_bits)) ++tri_bits;

@@ -219,6 +219,27 @@ def test_result_independent_of_shade_schedule(hip, monkeypatch):
                 assert counters(st) == ref[2]
 
 
+def test_result_independent_of_ray_ordering(hip, monkeypatch):
+    """The ray queue may be ordered by (kind of ray, source triangle, octant) before k_trace takes it (the default for scenes
+    whose tree does not fit the L2; JADE_SORT forces it either way): every result goes back to the ray's own slot, so image
+    and counters must not move by a bit."""
+    for name, spp in (("tinyjade", 16), ("C1", 4)):
+        hs, cfg = config_scene(name)
+        p = B.params_from_config(cfg, spp=spp)
+        p.width, p.height = 64, 48
+        ref = None
+        for sort in ("0", "1"):
+            monkeypatch.setenv("JADE_SORT", sort)
+            monkeypatch.setenv("JADE_SORT_MIN", "64")
+            with hip.scene(hs) as sc:
+                rgb, bgr, st = sc.render(p)
+            if ref is None:
+                ref = (rgb, bgr, counters(st))
+            else:
+                assert np.array_equal(rgb.view(np.uint32), ref[0].view(np.uint32)) and np.array_equal(bgr, ref[1])
+                assert counters(st) == ref[2]
+
+
 def test_many_samples_per_lane_match_oracle(oracle, hip):
     """spp > JADE_SAMPLE_LANES: several samples per lane, summed in lane order by both backends."""
     hs, cfg = config_scene("tiny")
