@@ -197,7 +197,10 @@ def main():
     for _ in range(args.steps):
         scene.step(spp_step, st)  # synchronous; a step may hand its last few paths to the next one (jade_rt.h)
     syncs_in_steps = int(st.host_syncs)
+    launches_in_steps = int(st.trace_launches)
+    tf = time.perf_counter()
     scene.flush(st)  # ... and the timed steps' own inside it: every sample of the K steps is done before the clock stops
+    flush_ms = (time.perf_counter() - tf) * 1e3
     barrier()
     dt = time.perf_counter() - t0
 
@@ -341,6 +344,8 @@ def main():
             # stops itself at the carry-over point), and in the flush that finishes the last paths of the render
             "host_syncs_per_step": syncs_in_steps / max(args.steps, 1),
             "host_syncs_in_final_flush": int(st.host_syncs) - syncs_in_steps,
+            # the flush that finishes the longest paths of the K steps (inside the timed region, once per render)
+            "final_flush": {"ms": flush_ms, "k_trace_launches": int(st.trace_launches) - launches_in_steps},
             "scene_build_s": build_s,
             "bvh": args.bvh, "device_bvh_ms": dev_build_ms,
             "nodes_per_ray": float(vals[1].item()) / rays_all, "tris_per_ray": float(vals[2].item()) / rays_all,
