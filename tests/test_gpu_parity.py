@@ -198,25 +198,28 @@ def test_result_independent_of_paths_in_flight(hip, monkeypatch):
 
 
 def test_result_independent_of_shade_schedule(hip, monkeypatch):
-    """A step's first pass is the fused k_light (light samples traced and shaded in one kernel) + k_shade over what it
-    hands over; JADE_FUSED=0 runs it as k_shade_lean + k_shade + k_trace passes instead, and JADE_SHADE_SPLIT=0 as k_shade
-    alone over the active list (what later passes use anyway).  Every bit of the result must be the same."""
+    """A step's first pass is fused: light samples traced and shaded in one kernel, the rays of a wave walked as one packet
+    (k_light_packet) or one lane per ray (k_light, JADE_LIGHT_PACKET=0), a packet given up after JADE_PACKET_BUDGET records
+    handed to the wavefront passes; JADE_FUSED=0 runs the first pass as k_shade_lean + k_shade + k_trace passes instead, and
+    JADE_SHADE_SPLIT=0 as k_shade alone over the active list (what later passes use anyway); list-mode passes run in
+    batches with device-side counts or one host wait per pass (JADE_BATCH).  Every bit of the result must be the same."""
     for name, spp in (("tinyjade", 24), ("C1", 6)):
         hs, cfg = config_scene(name)
         p = B.params_from_config(cfg, spp=spp)
         p.width, p.height = 40, 36
         ref = None
-        for split, fused, batch in (("1", "1", "1"), ("1", "0", "1"), ("0", "1", "1"), ("1", "1", "0")):
-            monkeypatch.setenv("JADE_SHADE_SPLIT", split)
-            monkeypatch.setenv("JADE_FUSED", fused)   # the step's first pass as the fused k_light, or as k_shade_lean + k_trace
-            monkeypatch.setenv("JADE_BATCH", batch)   # list-mode passes in batches (device-side counts), or one host sync per pass
+        #            split fused batch packet budget
+        for v in (("1", "1", "1", "1", "32"), ("1", "1", "1", "0", "32"), ("1", "1", "1", "1", "3"), ("1", "1", "1", "1", "100000"),
+                  ("1", "0", "1", "1", "32"), ("0", "1", "1", "1", "32"), ("1", "1", "0", "1", "32")):
+            for key, val in zip(("JADE_SHADE_SPLIT", "JADE_FUSED", "JADE_BATCH", "JADE_LIGHT_PACKET", "JADE_PACKET_BUDGET"), v):
+                monkeypatch.setenv(key, val)
             with hip.scene(hs) as sc:
                 rgb, bgr, st = sc.render(p)
             if ref is None:
                 ref = (rgb, bgr, counters(st))
             else:
-                assert np.array_equal(rgb.view(np.uint32), ref[0].view(np.uint32)) and np.array_equal(bgr, ref[1])
-                assert counters(st) == ref[2]
+                assert np.array_equal(rgb.view(np.uint32), ref[0].view(np.uint32)) and np.array_equal(bgr, ref[1]), v
+                assert counters(st) == ref[2], v
 
 
 def test_result_independent_of_ray_ordering(hip, monkeypatch):
