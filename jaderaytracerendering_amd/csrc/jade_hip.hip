@@ -1359,6 +1359,9 @@ struct DevEvent {  // an event that is destroyed on every return path
 #ifndef JADE_SORT_GEOMETRY_BYTES
 #define JADE_SORT_GEOMETRY_BYTES ((size_t)16 << 20) /* node + pair records above which the ray queue is ordered by default: four XCD L2s' worth */
 #endif
+#ifndef JADE_PACKET_GIVE_UP_LIMIT
+#define JADE_PACKET_GIVE_UP_LIMIT 0.25 /* share of a step's packets given up above which the next steps of the render use the per-lane first pass */
+#endif
 #ifndef JADE_PACKET_BUDGET
 #define JADE_PACKET_BUDGET 32 /* C3: k_light 153 / 159 / 167 / 181 ms per step at 16 / 32 / 64 / 128, and the step as a whole fastest at 32 (a lower budget hands more samples to the wavefront passes); C5: 32 / 33 / 36 ms at 16 / 32 / 64 */
 #endif
@@ -1422,6 +1425,7 @@ struct jade_scene {
   int trace_blocks = 0;
   int light_blocks = 0;       // persistent grid of k_light
   int packet_blocks = 0;      // ... and of k_light_packet (0: the tree is too deep for the packet form)
+  double packets_given_up = 0;  // share of the last fused pass's packets that were given up (reset by jade_render_begin)
   int64_t spp_done = 0;
   bool tail_pending = false;  // the last step left its longest paths unfinished (jade_render_flush)
   hipEvent_t ev[7] = {};      // run_passes' timing events, made once (ev0, ev1, ta, tb, sa, sb, sm)
@@ -1962,6 +1966,7 @@ int jade_render_begin(jade_scene* s, const jade_render_params* rp) {
   R.aspect = (double)rp->width / (double)rp->height;
   s->spp_done = 0;
   s->tail_pending = false;
+  s->packets_given_up = 0;
   if (npix64 == 0) { s->ps.npix = 0; s->ps.npx = 0; s->have_rp = true; return JADE_OK; }
   int rc = setup_state(s, (int)npx64, rpp, nslots, sum_lanes);
   if (rc) return rc;
@@ -2156,7 +2161,9 @@ static int run_passes(jade_scene* s, int64_t from_spp, uint32_t target_spp, bool
       HIP_TRY(hipEventRecord(s->ev_light[0], s->stream));
       light_timed = true;
       {
-        const bool packet = s->tun.light_packet && s->packet_blocks > 0;
+        // packets, unless the last step gave most of them up (a frame the statue fills: every packet fans out, and the per-lane
+        // kernel is then the better first pass - same bits, so the choice is free to make per step)
+        const bool packet = s->tun.light_packet && s->packet_blocks > 0 && s->packets_given_up < JADE_PACKET_GIVE_UP_LIMIT;
         const unsigned lb = (unsigned)std::min<size_t>((size_t)(packet ? s->packet_blocks : s->light_blocks), ((size_t)npix + JADE_TRACE_BLOCK - 1) / JADE_TRACE_BLOCK);
         const uint32_t n_waves = lb * (JADE_TRACE_BLOCK / 64);
         // a wave takes every n_waves-th chunk of 64 records: its region must hold all of them
@@ -2308,9 +2315,13 @@ static int advance(jade_scene* s, int64_t from0, bool may_carry, jade_stats* st)
     from = to;
     if (from >= s->spp_done) break;
   }
+  DevCounters c{};
+  HIP_TRY(sum_counters(s, &c));  // (32 KB: also read when the caller wants no statistics - the next step's choice of first pass depends on it)
+  if (c.pad[0]) s->packets_given_up = (double)c.pad[1] / (double)c.pad[0];
+  if (s->tun.log_passes && c.pad[0])
+    fprintf(stderr, "[jade] first pass: %llu packets, %llu given up and handed to the wavefront passes (%.2f %%)\n", (unsigned long long)c.pad[0],
+            (unsigned long long)c.pad[1], 100.0 * (double)c.pad[1] / (double)c.pad[0]);
   if (st) {
-    DevCounters c{};
-    HIP_TRY(sum_counters(s, &c));
     st->rays_primary += c.rays_primary;
     st->rays_secondary += c.rays_shadow + c.rays_env + c.rays_indirect + c.rays_mirror + c.rays_refract;
     st->rays_shadow += c.rays_shadow;
@@ -2326,9 +2337,6 @@ static int advance(jade_scene* s, int64_t from0, bool may_carry, jade_stats* st)
     st->tris_tested += c.tris_tested;
     st->shaded_hits += c.shaded_hits;
     st->samples += c.samples;
-    if (s->tun.log_passes && c.pad[0])
-      fprintf(stderr, "[jade] first pass: %llu packets, %llu given up and walked per lane (%.2f %%)\n", (unsigned long long)c.pad[0],
-              (unsigned long long)c.pad[1], 100.0 * (double)c.pad[1] / (double)c.pad[0]);
     st->kernel_ms += ms;
     st->trace_ms += trace_ms;
     st->trace_launches += launches;
