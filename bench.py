@@ -264,7 +264,8 @@ def main():
         rooflines = {
             "valu": roof_of("valu", c.get("valu_lane_ops_per_ray"), 1e12, VALU_PEAK_TLANEOPS, "Tlane-op/s",
                             {"valu_wave_insts_per_ray": c.get("valu_wave_insts_per_ray"), "lanes_per_valu_inst_of_64": c.get("lanes_per_valu_inst"),
-                             "issue_busy_of_2": c.get("valu_busy"),
+                             "issue_busy_of_2": c.get("valu_busy"), "valu2_share_of_valu_time": c.get("valu2_share_of_valu_time"),
+                             "frac_of_one_instruction_per_4_clocks": None,
                              "note": "peak = one wave64 VALU instruction per SIMD per 2 clocks (MI355X_MICROARCH.md: 2 cycles on a SIMD-32, which "
                                      "takes two or more waves per SIMD; ONE wave's own stream issues one per 4); issue_busy_of_2 = 4 x SQ_ACTIVE_INST_VALU / SIMD-cycles"}),
             "l2": roof_of("l2", (c.get("l2_requests_per_ray") or 0) * 64.0, 1e9, L2_GATHER_PEAK_GBS, "GB/s",
@@ -274,6 +275,8 @@ def main():
                            {"fetch_size_factor": c.get("fetch_size_factor"), "note": "FETCH_SIZE x fetch_size_factor + WRITE_SIZE per ray; the factor is what "
                             "tools/fetch_calib measured for 64-B gathers (profiles/fetch_calibration.json); Infinity-Cache hits are inside FETCH_SIZE"}),
         }
+        if rooflines["valu"]["frac"] is not None:  # the other reading of the VALU roof: one instruction per SIMD per 4 clocks
+            rooflines["valu"]["frac_of_one_instruction_per_4_clocks"] = 2.0 * rooflines["valu"]["frac"]
         for r in rooflines.values():
             r["counters_from"] = c.get("source")
             if r["bound"] == "hbm" and hbm_per_ray:

@@ -200,6 +200,10 @@ def main():
             e.update({"source": "profiles/%s_%ssq_summary.json + %s_%spmc_summary.json" % (tag, pre, tag, pre),
                       "valu_lane_ops_per_ray": kt.get("valu_lane_ops_per_ray"), "valu_wave_insts_per_ray": kt.get("valu_wave_insts_per_ray"),
                       "lanes_per_valu_inst": kt["lanes_per_valu_inst"], "valu_busy": kt["valu_busy"]})
+            sp = kt.get("second_pass") or {}
+            if sp.get("SQ_ACTIVE_INST_VALU2") and kt.get("SQ_INSTS_VALU"):
+                # quad-cycles in which two waves' VALU instructions were in execution together, per VALU instruction (1.007 quad-cycles each)
+                e["valu2_share_of_valu_time"] = sp["SQ_ACTIVE_INST_VALU2"] / (kt["SQ_INSTS_VALU"] * 1.007)
         if "pmc" in res and "k_trace_hbm_bytes_per_ray" in res["pmc"]:
             e.update({"hbm_bytes_per_ray": res["pmc"]["k_trace_hbm_bytes_per_ray"], "fetch_size_factor": GATHER_FETCH_FACTOR,
                       "l2_requests_per_ray": res["pmc"].get("k_trace_l2_requests_per_ray"), "l2_hit_rate": res["pmc"]["k_trace_l2_hit_rate"]})
