@@ -62,10 +62,28 @@
 #define JADE_RECORD_MEMORY 0.60 /* share of the free device memory that path records + partial sums may take: paths in \
                                   flight are what fills the wide passes (1080p on one GPU: 32 -> 256 records per pixel = +21 %) */
 
+// What shading needs of a triangle besides its vertices (round 3).  The reference copies an object's material into every
+// one of its triangles (PathTrace.cu:451: 76 of the 112 bytes of a Triangle_cu), and k_shade - bound by the number of 64-B
+// sectors it touches - read two to three sectors of such a record at every vertex, hit and exit point, most of them misses
+// (the triangles a path meets are all over the statue).  jade_scene_create keeps the distinct {object, material} tuples in a
+// table (a handful of entries for any scene the reference can load: L1-resident) and 16 bytes per triangle: the flat normal
+// and the tuple's number.  The values are the bytes of the caller's records; only where they are read from differs.
+struct DevMaterial {  // 64 bytes; field names as in jade_triangle
+  float emissive[3];
+  float brdf[3];
+  int32_t reflex_mode, refract_mode;
+  float refract_rate[3];
+  float refract_albedo[3];
+  float refract_index;
+  int32_t obj_idx;
+};
+
 struct DevScene {
   const float4* nodes;        // 4 x float4 per internal node
   const float4* tverts;       // 5 x float4 per pair of triangles of a leaf (jade_trace.h)
-  const jade_triangle* tris;  // shading records (BVH order)
+  const jade_triangle* tris;  // the caller's records (BVH order): read for vertices only (emitters, the BSSRDF exit triangle)
+  const float4* tnorm;        // per triangle {flat normal, number of its DevMaterial (uint bits)}
+  const DevMaterial* mats;
   const int32_t* emit;
   const int32_t* mapping;
   const float* prefix;

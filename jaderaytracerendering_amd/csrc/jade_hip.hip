@@ -26,6 +26,7 @@
 #include <rccl/rccl.h>  // types only: the library is loaded on first use (jade_render_multi on distinct devices)
 
 #include <algorithm>
+#include <map>
 #include <thread>
 #include <cstdio>
 #include <cstring>
@@ -233,7 +234,7 @@ static __device__ __forceinline__ void shade_record(const DevScene& S, const Pat
         c.thr = jv(b0.x, b0.y, b0.z);
         c.acc = jv(b1.x, b1.y, b1.z);
       }
-      if (st == ST_MIRROR && c.depth == 0) c.le = V3(S.tris[c.obj].emissive);
+      if (st == ST_MIRROR && c.depth == 0) c.le = V3(shade_tri(S, c.obj).m->emissive);
       else c.le = jv(b2.x, b2.y, b2.z);
       if (st != ST_MIRROR) {
         c.src = jv(b2.w, b3.x, b3.y);
@@ -253,7 +254,7 @@ static __device__ __forceinline__ void shade_record(const DevScene& S, const Pat
         color = sample_hdr(S, d);  // PathTrace.cu:1443-1445
         finished = true;
       } else {
-        c.le = V3(S.tris[h].emissive);
+        c.le = V3(shade_tri(S, h).m->emissive);
         c.thr = jv(1, 1, 1);
         c.acc = jv(0, 0, 0);
         c.depth = 0;
@@ -291,7 +292,7 @@ static __device__ __forceinline__ void shade_record(const DevScene& S, const Pat
         st = ST_IDLE;
       }
       if (st == ST_VERTEX) {
-        if (LEAN && !lean_can_shade(&S.tris[c.obj])) {  // jade / diffuse / glass: the full kernel continues from here
+        if (LEAN && !lean_can_shade(shade_tri(S, c.obj).m)) {  // jade / diffuse / glass: the full kernel continues from here
           defer = true;
           break;
         }
@@ -795,7 +796,7 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_LIGHT_WAVES) void k_light(De
                 color = sample_hdr(S, rp.d);  // PathTrace.cu:1443-1445
                 finished = true;
               } else {
-                c.le = V3(S.tris[rp.h].emissive);
+                c.le = V3(shade_tri(S, rp.h).m->emissive);
                 c.thr = jv(1, 1, 1);
                 c.acc = jv(0, 0, 0);
                 c.depth = 0;
@@ -828,7 +829,7 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_LIGHT_WAVES) void k_light(De
               st = ST_IDLE;
             }
             if (st == ST_VERTEX) {
-              if (!lean_can_shade(&S.tris[c.obj])) {  // jade / diffuse / glass: k_shade continues from here
+              if (!lean_can_shade(shade_tri(S, c.obj).m)) {  // jade / diffuse / glass: k_shade continues from here
                 defer = true;
                 mine = false;
                 break;
@@ -1033,7 +1034,7 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_PACKET_WAVES) void k_light_p
             st = ST_IDLE;
           }
           if (st == ST_VERTEX) {
-            if (!lean_can_shade(&S.tris[c.obj])) {  // jade / diffuse / glass: k_shade continues from here
+            if (!lean_can_shade(shade_tri(S, c.obj).m)) {  // jade / diffuse / glass: k_shade continues from here
               defer = true;
               mine = false;
               break;
@@ -1130,7 +1131,7 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_PACKET_WAVES) void k_light_p
             finished = true;
             st = ST_IDLE;
           } else {
-            c.le = V3(S.tris[rp.h].emissive);
+            c.le = V3(shade_tri(S, rp.h).m->emissive);
             c.thr = jv(1, 1, 1);
             c.acc = jv(0, 0, 0);
             c.depth = 0;
@@ -1408,7 +1409,7 @@ struct jade_scene {
   Tunables tun;
   hipStream_t stream = nullptr;
   DevScene dev{};
-  DevBuf b_nodes, b_tverts, b_tris, b_emit, b_mapping, b_prefix, b_segs, b_env, b_guide, b_guide_obj;
+  DevBuf b_nodes, b_tverts, b_tris, b_emit, b_mapping, b_prefix, b_segs, b_env, b_guide, b_guide_obj, b_tnorm, b_mats;
   int n_emit = 0;
   int bvh_depth = 0;
   bool sort_rays = false;     // the ray queue is ordered before every k_trace launch (Tunables.sort_mode; then passes are host-followed)
@@ -1758,6 +1759,48 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
   }
   if (guide.empty()) guide.push_back(0u);
 
+  // What shading reads of a triangle (jade_device.h, DevMaterial): the distinct {object, material} tuples of the caller's
+  // records - the reference copies an object's material into each of its triangles, PathTrace.cu:451 - and per triangle
+  // the flat normal + the number of its tuple.  Same bytes, read from 16 B + a cached table instead of a 112-B record.
+  std::vector<DevMaterial> mats;
+  std::vector<float4> tnorm((size_t)d->n_triangles);
+  {
+    std::map<std::string, uint32_t> seen;  // key: the 64 bytes of the tuple
+    std::string last_key;
+    uint32_t last_id = 0;
+    for (int i = 0; i < d->n_triangles; ++i) {
+      const jade_triangle& t = d->triangles[i];
+      DevMaterial m;
+      memcpy(m.emissive, t.emissive, 12);
+      memcpy(m.brdf, t.brdf, 12);
+      m.reflex_mode = t.reflex_mode;
+      m.refract_mode = t.refract_mode;
+      memcpy(m.refract_rate, t.refract_rate, 12);
+      memcpy(m.refract_albedo, t.refract_albedo, 12);
+      m.refract_index = t.refract_index;
+      m.obj_idx = t.obj_idx;
+      std::string key(reinterpret_cast<const char*>(&m), sizeof m);
+      uint32_t id;
+      if (i > 0 && key == last_key) {
+        id = last_id;
+      } else {
+        auto it = seen.find(key);
+        if (it == seen.end()) {
+          id = (uint32_t)mats.size();
+          mats.push_back(m);
+          seen.emplace(key, id);
+        } else {
+          id = it->second;
+        }
+        last_key = std::move(key);
+        last_id = id;
+      }
+      float idf;
+      memcpy(&idf, &id, 4);
+      tnorm[(size_t)i] = make_float4(t.norm[0], t.norm[1], t.norm[2], idf);
+    }
+  }
+
   jade_scene* s = new (std::nothrow) jade_scene();
   if (!s) return fail(JADE_ERR_NOMEM, "out of memory");
   s->device = device_id;
@@ -1773,6 +1816,8 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
   if (e == hipSuccess) e = upload(s->b_prefix, d->prefix_area, (size_t)d->n_triangles, s->stream);
   if (e == hipSuccess) e = upload(s->b_segs, d->obj_segs, (size_t)d->n_objects, s->stream);
   if (e == hipSuccess) e = upload(s->b_env, d->env_rgb, (size_t)3 * d->env_width * d->env_height, s->stream);
+  if (e == hipSuccess) e = upload(s->b_tnorm, tnorm.data(), tnorm.size(), s->stream);
+  if (e == hipSuccess) e = upload(s->b_mats, mats.data(), mats.size(), s->stream);
   if (e == hipSuccess) e = upload(s->b_guide, guide.data(), guide.size(), s->stream);
   if (e == hipSuccess) e = upload(s->b_guide_obj, guide_obj.data(), guide_obj.size(), s->stream);
   if (e == hipSuccess) e = s->b_ctl.alloc(sizeof(QueueCtl) * JADE_CTL_RING);
@@ -1789,6 +1834,8 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
   s->dev.prefix = s->b_prefix.as<float>();
   s->dev.segs = s->b_segs.as<jade_obj_seg>();
   s->dev.env = s->b_env.as<float>();
+  s->dev.tnorm = s->b_tnorm.as<float4>();
+  s->dev.mats = s->b_mats.as<DevMaterial>();
   s->dev.guide = s->b_guide.as<uint32_t>();
   s->dev.guide_obj = s->b_guide_obj.as<uint2>();
   s->dev.env_w = d->env_width;

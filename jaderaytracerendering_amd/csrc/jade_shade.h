@@ -79,7 +79,20 @@ static __device__ __forceinline__ float tri_size(const jade_triangle* t) {  // P
   return 0.5f * jade_sqrt(jv_dot(cp, cp));
 }
 
-static __device__ __forceinline__ bool nonemissive(const jade_triangle* t) {
+// a triangle as shading sees it: its flat normal and its object's material (jade_device.h, DevMaterial)
+struct ShadeTri {
+  jvec3 norm;
+  const DevMaterial* m;
+};
+static __device__ __forceinline__ ShadeTri shade_tri(const DevScene& S, int idx) {
+  const float4 v = S.tnorm[idx];
+  ShadeTri t;
+  t.norm = jv(v.x, v.y, v.z);
+  t.m = S.mats + __float_as_uint(v.w);
+  return t;
+}
+
+static __device__ __forceinline__ bool nonemissive(const DevMaterial* t) {
   return t->emissive[0] < 1.5e-4f && t->emissive[1] < 1.5e-4f && t->emissive[2] < 1.5e-4f;
 }
 
@@ -185,7 +198,7 @@ static __device__ __forceinline__ bool path_push(ShadeCtx& c, jvec3 dirv, jvec3 
 // The mirror branch of the bounce loop (PathTrace.cu:1365-1405): RR, then the reflected ray.
 // Shared by the full shading kernel and the lean one (k_shade<true>).
 template <class PX>
-static __device__ __forceinline__ bool bounce_mirror(PX& px, ShadeCtx& c, const jade_triangle* ot, jvec3 obj_emissive, jvec3 n,
+static __device__ __forceinline__ bool bounce_mirror(PX& px, ShadeCtx& c, const DevMaterial* ot, jvec3 obj_emissive, jvec3 n,
                                                      jvec3* l_final) {
   const float RR_F = (float)JADE_RR_RATE_D;
   jvec3 obj_hit_fr = jv_scale(V3(ot->brdf), (float)(1.0 / JADE_PI_D));
@@ -208,7 +221,7 @@ static __device__ __forceinline__ bool bounce_mirror(PX& px, ShadeCtx& c, const 
 
 // What the lean kernel may shade at a vertex: an emitter (the loop's first test ends the path) or a
 // pure mirror (no refraction branch, not diffuse).  Everything else needs the full kernel.
-static __device__ __forceinline__ bool lean_can_shade(const jade_triangle* ot) {
+static __device__ __forceinline__ bool lean_can_shade(const DevMaterial* ot) {
   if (ot->emissive[0] > 1.4e-5f || ot->emissive[1] > 1.4e-5f || ot->emissive[2] > 1.4e-5f) return true;
   return ot->refract_mode == JADE_NO_REFRACT && ot->reflex_mode != JADE_DIFFUSE;
 }
@@ -217,7 +230,8 @@ static __device__ __forceinline__ bool lean_can_shade(const jade_triangle* ot) {
 // (emissive test :916-920, the select draw :924, then the mirror branch).
 template <class PX>
 static __device__ bool begin_bounce_lean(const DevScene& S, PX& px, ShadeCtx& c, jvec3* l_final) {
-  const jade_triangle* ot = &S.tris[c.obj];
+  const ShadeTri ots = shade_tri(S, c.obj);
+  const DevMaterial* ot = ots.m;
   c.c_shaded += 1;
   jvec3 obj_emissive = V3(ot->emissive);
   if (obj_emissive.x > 1.4e-5f || obj_emissive.y > 1.4e-5f || obj_emissive.z > 1.4e-5f) {
@@ -226,14 +240,15 @@ static __device__ bool begin_bounce_lean(const DevScene& S, PX& px, ShadeCtx& c,
   }
   *l_final = jv(0, 0, 0);
   (void)jade_rand(&c.rng);  // select_reflex_refract: drawn for every material, decides nothing for a pure mirror
-  return bounce_mirror(px, c, ot, obj_emissive, V3(ot->norm), l_final);
+  return bounce_mirror(px, c, ot, obj_emissive, ots.norm, l_final);
 }
 
 // Sample the bounce at the current vertex and emit its rays.  Returns false
 // if the path ended at this vertex (l_final holds the last l_dir).
 static __device__ bool begin_bounce(const DevScene& S, const Px& px, ShadeCtx& c, jvec3* l_final) {
-  const jade_triangle* T = S.tris;
-  const jade_triangle* ot = &T[c.obj];
+  const jade_triangle* T = S.tris;  // vertices only
+  const ShadeTri ots = shade_tri(S, c.obj);
+  const DevMaterial* ot = ots.m;
   const int nE = S.n_emit;
   const float RR_F = (float)JADE_RR_RATE_D;
   c.c_shaded += 1;
@@ -243,7 +258,7 @@ static __device__ bool begin_bounce(const DevScene& S, const Px& px, ShadeCtx& c
     return false;
   }
   *l_final = jv(0, 0, 0);
-  const jvec3 n = V3(ot->norm);
+  const jvec3 n = ots.norm;
   float select_reflex_refract = jade_rand(&c.rng);
   if (select_reflex_refract < 0.5f && ot->refract_mode != JADE_NO_REFRACT) {
     if (ot->refract_mode == JADE_SUB_SURFACE) {
@@ -292,10 +307,11 @@ static __device__ bool begin_bounce(const DevScene& S, const Px& px, ShadeCtx& c
         rand_x = 1 - rand_x;
         rand_y = 1 - rand_y;
       }
-      const jade_triangle* t_i = &T[middle];
-      const jvec3 t_norm = V3(t_i->norm);
+      const ShadeTri t_is = shade_tri(S, middle);
+      const DevMaterial* t_i = t_is.m;
+      const jvec3 t_norm = t_is.norm;
       const jvec3 rate = V3(t_i->refract_rate);
-      jvec3 random_point = tri_point(t_i, rand_x, rand_y);
+      jvec3 random_point = tri_point(&T[middle], rand_x, rand_y);
       jvec3 inner_direction = jv_sub(random_point, c.src);
       float inner_distance = jade_sqrt(jv_dot(inner_direction, inner_direction));
       float neg_d = -1.0f * inner_distance;
@@ -426,7 +442,7 @@ enum { CONSUME_VERTEX = 0, CONSUME_END = 1, CONSUME_ZERO = 2, CONSUME_EMITTED = 
 // Result of the mirror ray (PathTrace.cu:1383-1398).  Shared by both shading kernels.
 template <class PX>
 static __device__ __forceinline__ int consume_mirror(const DevScene& S, const PX& px, ShadeCtx& c, jvec3* l_final) {
-  const jade_triangle* ot = &S.tris[c.obj];
+  const DevMaterial* ot = shade_tri(S, c.obj).m;
   const int k = ot->refract_mode != JADE_NO_REFRACT ? 2 : 1;
   const jvec3 obj_hit_fr = jv_scale(V3(ot->brdf), (float)(1.0 / JADE_PI_D));
   float kk = (float)(k / (JADE_RR_RATE_D / JADE_PI_D));
@@ -448,12 +464,13 @@ static __device__ __forceinline__ int consume_mirror(const DevScene& S, const PX
 // *l_final; CONSUME_ZERO: pathTracing returned 0 (:1231); CONSUME_EMITTED: the
 // refraction loop issued its next ray.
 static __device__ int consume(const DevScene& S, const Px& px, ShadeCtx& c, jvec3* l_final) {
-  const jade_triangle* T = S.tris;
+  const jade_triangle* T = S.tris;  // vertices only
   const int nE = S.n_emit;
   const float PI_F = (float)JADE_PI_D;
   const float RR_F = (float)JADE_RR_RATE_D;
-  const jade_triangle* ot = &T[c.obj];
-  const jvec3 n = V3(ot->norm);
+  const ShadeTri ots = shade_tri(S, c.obj);
+  const DevMaterial* ot = ots.m;
+  const jvec3 n = ots.norm;
   const int k = ot->refract_mode != JADE_NO_REFRACT ? 2 : 1;
   const jvec3 obj_hit_fr = jv_scale(V3(ot->brdf), (float)(1.0 / JADE_PI_D));
   jvec3 l_dir = jv(0, 0, 0);
@@ -466,12 +483,12 @@ static __device__ int consume(const DevScene& S, const Px& px, ShadeCtx& c, jvec
       int emit_tri_idx = S.emit[i];
       if (h >= 0 && h == emit_tri_idx) {
         jvec3 ld = px.dir(i);
-        const jade_triangle* t_i = &T[emit_tri_idx];
+        const ShadeTri t_i = shade_tri(S, emit_tri_idx);
         float dls = jv_dot(ld, ld);
-        jvec3 w = jv_mul(V3(t_i->emissive), f);
-        w = jv_scale(w, jade_fabs(jv_dot(n, ld) * jv_dot(V3(t_i->norm), ld)));
+        jvec3 w = jv_mul(V3(t_i.m->emissive), f);
+        w = jv_scale(w, jade_fabs(jv_dot(n, ld) * jv_dot(t_i.norm, ld)));
         w = jv_divs(jv_divs(w, dls), dls);
-        w = jv_scale(w, tri_size(t_i));
+        w = jv_scale(w, tri_size(&T[emit_tri_idx]));
         l_dir = jv_add(l_dir, w);
       }
     }
@@ -486,7 +503,7 @@ static __device__ int consume(const DevScene& S, const Px& px, ShadeCtx& c, jvec
     *l_final = l_dir;
     if (!(c.flags & STF_RR)) return CONSUME_END;
     int nh = px.hit(nE + 1);
-    if (nh >= 0 && nonemissive(&T[nh])) {
+    if (nh >= 0 && nonemissive(shade_tri(S, nh).m)) {
       jvec3 rd = jv_neg(px.dir(nE + 1));
       jvec3 indir_rate = jv_divs(jv_scale(obj_hit_fr, jade_fabs(jv_dot(rd, n))), RR_F);
       jvec3 rate = sss ? jv_divs(jv_scale(indir_rate, (float)k), (float)JADE_SSS_RATE_D) : jv_scale(indir_rate, (float)k);
@@ -500,8 +517,9 @@ static __device__ int consume(const DevScene& S, const Px& px, ShadeCtx& c, jvec
 
   if (c.stage == ST_BSSRDF) {
     const int middle = px.skip();
-    const jade_triangle* t_i = &T[middle];
-    const jvec3 t_norm = V3(t_i->norm);
+    const ShadeTri t_is = shade_tri(S, middle);
+    const DevMaterial* t_i = t_is.m;
+    const jvec3 t_norm = t_is.norm;
     const jvec3 bssrdf = px.aux();
     const float eta = t_i->refract_index;
     const float R0 = (eta - 1) / (eta + 1) * (eta - 1) / (eta + 1);
@@ -511,14 +529,14 @@ static __device__ int consume(const DevScene& S, const Px& px, ShadeCtx& c, jvec
       int emit_tri_idx = S.emit[i];
       if (h >= 0 && h == emit_tri_idx) {
         jvec3 ld = px.dir(i);
-        const jade_triangle* emit_i = &T[emit_tri_idx];
+        const ShadeTri emit_i = shade_tri(S, emit_tri_idx);
         float fresnel_rate_o = schlick_out(R0, jade_fabs(jv_dot(jv_normalize(ld), t_norm)));
         float dls = jv_dot(ld, ld);
-        jvec3 w = jv_scale(V3(emit_i->emissive), fresnel_rate_o);
+        jvec3 w = jv_scale(V3(emit_i.m->emissive), fresnel_rate_o);
         w = jv_mul(w, bssrdf);
-        w = jv_scale(w, jade_fabs(jv_dot(t_norm, ld) * jv_dot(V3(emit_i->norm), ld)));
+        w = jv_scale(w, jade_fabs(jv_dot(t_norm, ld) * jv_dot(emit_i.norm, ld)));
         w = jv_divs(jv_divs(w, dls), dls);
-        w = jv_scale(w, tri_size(emit_i));
+        w = jv_scale(w, tri_size(&T[emit_tri_idx]));
         w = jv_divs(w, PI_F);
         w = jv_scale(w, area_total);
         l_dir = jv_add(l_dir, w);
@@ -535,7 +553,7 @@ static __device__ int consume(const DevScene& S, const Px& px, ShadeCtx& c, jvec
     *l_final = l_dir;
     if (!(c.flags & STF_RR)) return CONSUME_END;
     int nh = px.hit(nE + 1);
-    if (nh >= 0 && nonemissive(&T[nh])) {
+    if (nh >= 0 && nonemissive(shade_tri(S, nh).m)) {
       jvec3 rd = jv_neg(px.dir(nE + 1));
       float fresnel_rate_o = schlick_out(R0, jade_fabs(jv_dot(rd, t_norm)));
       jvec3 indir_rate = jv_scale(bssrdf, fresnel_rate_o);
@@ -559,8 +577,9 @@ static __device__ int consume(const DevScene& S, const Px& px, ShadeCtx& c, jvec
     const float R0 = (1 - triangle_miu) / (1 + triangle_miu) * (1 - triangle_miu) / (1 + triangle_miu);
     int nh = px.hit(0);
     if (nh < 0) return CONSUME_ZERO;  // "obj surface is not close": return vec3(0)
-    const jade_triangle* ht = &T[nh];
-    const jvec3 hn = V3(ht->norm);
+    const ShadeTri hts = shade_tri(S, nh);
+    const DevMaterial* ht = hts.m;
+    const jvec3 hn = hts.norm;
     jvec3 refract_ray = px.dir(0);
     jvec3 start = px.origin();
     jvec3 hp = px.hpt(0);

@@ -1,7 +1,7 @@
 #!/bin/bash
-# round 3, GPU call 10: {origin + context} in one 128-B block, adaptive first pass: parity, then against the build before
+# round 3, GPU call 11: compact shading records (normal + material table) against the build before
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O="$R/gpurun_out/r03_c10"; mkdir -p "$O"; cd "$R"
+O="$R/gpurun_out/r03_c11"; mkdir -p "$O"; cd "$R"
 timeout -k 10 600 python3 -m pytest tests -m gpu -x -q -k "golden or parity or packet or edge or spec or scene_io or bench_schedule" > "$O/pytest.log" 2>&1
 rc=$?; tail -3 "$O/pytest.log"
 if [ $rc -ne 0 ]; then echo "parity failed: stopping"; tail -40 "$O/pytest.log"; exit $rc; fi
@@ -19,9 +19,9 @@ PY
 A="--steps 3 --warmup 1 --no-cpu-baseline"
 L="$R/jaderaytracerendering_amd/lib"
 JADE_HIP_LIB=$L/libjade_hip_old.so timeout -k 10 300 python3 bench.py $A > "$O/old.json" 2> "$O/old.err"; show "$O/old.json" "before"
-timeout -k 10 300 python3 bench.py $A > "$O/new.json" 2> "$O/new.err"; show "$O/new.json" "packed block"
+timeout -k 10 300 python3 bench.py $A > "$O/new.json" 2> "$O/new.err"; show "$O/new.json" "compact shading"
 JADE_HIP_LIB=$L/libjade_hip_old.so timeout -k 10 300 python3 bench.py $A > "$O/old2.json" 2> "$O/old2.err"; show "$O/old2.json" "before (2)"
-timeout -k 10 300 python3 bench.py $A > "$O/new2.json" 2> "$O/new2.err"; show "$O/new2.json" "packed block (2)"
+timeout -k 10 300 python3 bench.py $A > "$O/new2.json" 2> "$O/new2.err"; show "$O/new2.json" "compact shading (2)"
 C5="--config C5 --steps 2 --warmup 1 --spp-per-step 64 --no-cpu-baseline --no-extras"
 JADE_HIP_LIB=$L/libjade_hip_old.so timeout -k 10 300 python3 bench.py $C5 > "$O/c5_old.json" 2> "$O/c5_old.err"; show "$O/c5_old.json" "C5 before"
-timeout -k 10 300 python3 bench.py $C5 > "$O/c5_new.json" 2> "$O/c5_new.err"; show "$O/c5_new.json" "C5 packed block"
+timeout -k 10 300 python3 bench.py $C5 > "$O/c5_new.json" 2> "$O/c5_new.err"; show "$O/c5_new.json" "C5 compact shading"
