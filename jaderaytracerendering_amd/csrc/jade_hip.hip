@@ -597,6 +597,10 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
 #endif
   WaveTrace wt;  // the wave's rings of leaves to test and of hit candidates, and the item this lane is testing (jade_trace.h)
   wt.init(lds_addr_of(&lds_wq[threadIdx.x >> 6][0]), lds_addr_of(&lds_hq[threadIdx.x >> 6][0]), lane);
+#if JADE_COOP_LEAF
+  __shared__ __attribute__((aligned(16))) uint32_t lds_stage[JADE_TRACE_BLOCK / 64][64 * 20];
+  wt.stage = lds_addr_of(&lds_stage[threadIdx.x >> 6][0]);
+#endif
   TraceProf pr;
 #if JADE_TRACE_PROFILE
   __shared__ __attribute__((aligned(8))) unsigned long long lds_prof[JADE_TRACE_BLOCK / 64][PL_N];

@@ -744,7 +744,13 @@ static __device__ __forceinline__ int32_t walk_result(const LdsStack& stk, const
 // A wave's side of the scheme above: its two rings, the item each lane is testing, and one iteration of work.  Used by
 // k_trace (rays from the queue) and k_light (rays from the lane's own path): everything in here is wave-uniform control
 // flow around the per-lane steps.
+#ifndef JADE_COOP_LEAF
+#define JADE_COOP_LEAF 0 /* 1: development variant (north_star: "triangle SoA staged through LDS"): a test unit's 64 pair records are fetched by the wave cooperatively - lanes 5r .. 5r+4 read the five 16-B parts of lane r's record, 80 contiguous bytes - into a 5 KB stage in LDS, from which every lane reads its own record.  Measured, not shipped */
+#endif
 struct WaveTrace {
+#if JADE_COOP_LEAF
+  uint32_t stage;                // LDS byte address of this wave's 64 x 80-B stage
+#endif
   uint32_t wq, hq;               // LDS byte addresses of the ring of leaves and of the ring of candidates
   uint32_t q_head, q_count;      // leaves waiting (wave-uniform)
   uint32_t h_head, h_count;      // candidates waiting (wave-uniform)
@@ -876,7 +882,26 @@ struct WaveTrace {
         // the record first (it depends on the item alone), then the ray the item belongs to
         const uint32_t off = item_leaf & 0x7ffffff0u;
         PairRec rec;
+#if JADE_COOP_LEAF
+        {
+          const uint32_t myoff = go ? off : 0u;  // (a lane without an item stages record 0: never read)
+#pragma unroll
+          for (uint32_t j = 0; j < 5u; ++j) {
+            const uint32_t c = j * 64u + (uint32_t)lane, rr = c / 5u, part = c - 5u * rr;
+            const uint32_t o_r = (uint32_t)__shfl((int)myoff, (int)rr, 64);
+            const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.tverts) + o_r + 16u * part);
+            *(__attribute__((address_space(3))) float4*)(__SIZE_TYPE__)(stage + 16u * c) = v;
+          }
+          const __attribute__((address_space(3))) float4* mine = (const __attribute__((address_space(3))) float4*)(__SIZE_TYPE__)(stage + 80u * (uint32_t)lane);
+          rec.q0 = mine[0];
+          rec.q1 = mine[1];
+          rec.q2 = mine[2];
+          rec.q3 = mine[3];
+          rec.q4 = mine[4];
+        }
+#else
         if (go) rec = pair_load(S, off);
+#endif
         PROF_DRAIN();
         PROF_LAP(pr, PL_TEST_LOAD);
         const int owner = (int)(item_meta & 63u);
