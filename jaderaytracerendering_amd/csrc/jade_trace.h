@@ -890,14 +890,18 @@ struct WaveTrace {
             const uint32_t c = j * 64u + (uint32_t)lane, rr = c / 5u, part = c - 5u * rr;
             const uint32_t o_r = (uint32_t)__shfl((int)myoff, (int)rr, 64);
             const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.tverts) + o_r + 16u * part);
-            *(__attribute__((address_space(3))) float4*)(__SIZE_TYPE__)(stage + 16u * c) = v;
+            typedef float coop_f4 __attribute__((ext_vector_type(4)));
+            const coop_f4 nv = {v.x, v.y, v.z, v.w};
+            *(__attribute__((address_space(3))) coop_f4*)(__SIZE_TYPE__)(stage + 16u * c) = nv;
           }
-          const __attribute__((address_space(3))) float4* mine = (const __attribute__((address_space(3))) float4*)(__SIZE_TYPE__)(stage + 80u * (uint32_t)lane);
-          rec.q0 = mine[0];
-          rec.q1 = mine[1];
-          rec.q2 = mine[2];
-          rec.q3 = mine[3];
-          rec.q4 = mine[4];
+          typedef float coop_f4 __attribute__((ext_vector_type(4)));
+          const __attribute__((address_space(3))) coop_f4* mine = (const __attribute__((address_space(3))) coop_f4*)(__SIZE_TYPE__)(stage + 80u * (uint32_t)lane);
+          const coop_f4 m0 = mine[0], m1 = mine[1], m2 = mine[2], m3 = mine[3], m4 = mine[4];
+          rec.q0 = make_float4(m0.x, m0.y, m0.z, m0.w);
+          rec.q1 = make_float4(m1.x, m1.y, m1.z, m1.w);
+          rec.q2 = make_float4(m2.x, m2.y, m2.z, m2.w);
+          rec.q3 = make_float4(m3.x, m3.y, m3.z, m3.w);
+          rec.q4 = make_float4(m4.x, m4.y, m4.z, m4.w);
         }
 #else
         if (go) rec = pair_load(S, off);
