@@ -108,15 +108,21 @@ def profile_json(name):
         return None
 
 
-def csrc_hash():
-    """sha256 over the sources the device code is built from (tools/summarize_prof.py stamps the counter files with it)."""
+def csrc_hash(read=None):
+    """sha256 over the CODE the device side is built from - csrc/*.h, *.hip and the two shared headers with comments and blank
+    space stripped, so that editing a comment does not orphan the counter files (tools/summarize_prof.py stamps them with it)."""
     import glob
     import hashlib
+    import re
     h = hashlib.sha256()
     files = sorted(glob.glob(os.path.join(ROOT, "jaderaytracerendering_amd", "csrc", "*.h*"))) + [os.path.join(ROOT, "include", n) for n in ("jade_fpmath.h", "jade_rt.h")]
     for f in files:
+        text = (read or (lambda path: open(path, errors="replace").read()))(f)
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)      # block comments
+        text = re.sub(r"//[^\n]*", " ", text)                    # line comments (no string literal of these sources holds "//")
+        text = re.sub(r"\s+", " ", text).strip()
         h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+        h.update(text.encode())
     return h.hexdigest()[:16]
 
 

@@ -3,18 +3,20 @@
 // Replaces PathTrace.cu:1618-1741 (upload, constants, RNG init, the single
 // render_pixel launch, sync, download).  Kernel structure (one HIP stream):
 //
-//   k_init        resets the path records, clears the partial sums
-//   k_arm         lists the records that have work in a step (record order)
-//   k_shade_lean  camera rays, the sky and pure mirrors, over ALL records in record
-//                 order (52 VGPRs, 8 waves/SIMD): folds last pass's hit results
-//                 into the path, starts the next sample when a path ends, emits
-//                 rays into a compacted queue (wave prefix sums + one 64-bit
-//                 atomic per block); hands every other record to k_shade
-//   k_shade       every branch of pathTracing, over the hand-over list or (once few
-//                 records are active) over the active list
-//   k_trace       persistent workgroups claim chunks of the queue and run the BVH
-//                 traversal (jade_trace.h) — the dominant kernel
-//   k_resolve     adds the partial sums; mean, ACES, gamma, BGR8 pack (PathTrace.cu:1457-1473)
+//   k_init          resets the path records (the partial sums are cleared with the allocation)
+//   k_light_packet  a step's FIRST pass, fused: camera rays, the sky, emitters and pure mirrors traced and shaded in one
+//                   kernel, a wave's 64 rays walked together as a packet (jade_trace.h); records that meet jade / diffuse /
+//                   glass, or whose packet fans out, are handed to k_shade.  k_light: the same pass, one lane per ray
+//                   (trees deeper than 63, frames the statue fills); k_heavy_scan / k_heavy_pack close the hand-over list
+//   k_shade         every branch of pathTracing, over the hand-over list, then over the active list: folds last pass's hit
+//                   results into the path, starts the next sample when a path ends, emits the next bounce's rays into a
+//                   compacted queue (wave prefix sums + one 64-bit atomic per block)
+//   k_ray_keys      (+ rocPRIM pairs sort) orders the queue for scenes whose tree does not fit the L2
+//   k_trace         persistent workgroups claim chunks of the queue and run the BVH traversal (jade_trace.h) - the
+//                   dominant kernel
+//   k_resolve       adds the partial sums; mean, ACES, gamma, BGR8 pack (PathTrace.cu:1457-1473)
+//   k_arm / k_shade_lean  list the records with work / shade light samples over all records: the schedules without the
+//                   fused pass (flushes, JADE_FUSED=0)
 //
 // shade/trace alternate until a shade pass emits nothing (every path record has
 // finished its samples), or until so few are active that the step hands them to the
