@@ -84,6 +84,9 @@ def parse():
     ap.add_argument("--cpu-spp", type=int, default=8, help="oracle sample: spp over the full frame")
     ap.add_argument("--max-state-gb", type=float, default=0.0, help="jade_render_params.max_state_bytes: device memory for path records + partial sums (0 = the default, 60 %% of what is free)")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle spot check of the rendered frame")
+    ap.add_argument("--reference-walk", action="store_true",
+                    help="jade_render_params.walk = JADE_WALK_REFERENCE in the timed region: every query walks what the reference walks "
+                         "(the default, JADE_WALK_EARLY_EXIT, ends shadow / environment-visibility walks at the hit that settles them: the same frame, bit for bit)")
     ap.add_argument("--parity-rays", type=float, default=1.2e8, help="oracle rays the parity check may cost (about 7 Mray/s on 16 cores)")
     return ap.parse_args()
 
@@ -173,8 +176,9 @@ def main():
     if args.virtual_ranks > 1 and world == 1:
         part_world, part_rank = args.virtual_ranks, 0
     spp_step = args.spp_per_step * part_world  # weak scaling: fixed work per GPU per step
+    walk = _abi.WALK_REFERENCE if args.reference_walk else _abi.WALK_EARLY_EXIT
     params = B.make_params(width, height, spp_step, list(cfg.eye), list(cfg.camera), tile_rank=part_rank,
-                           tile_nranks=part_world, device_id=local_rank)
+                           tile_nranks=part_world, device_id=local_rank, walk=walk)
     if rehearsal and world > 1:  # ranks share one GPU: each may hold its share of the memory, not 60 % of what is free
         params.max_state_bytes = int(0.6 * torch.cuda.mem_get_info(local_rank)[0] / world)
     if args.max_state_gb > 0:
@@ -238,12 +242,46 @@ def main():
     dt = float(tmax.item())
     rays_all = float(vals[0].item())
 
+    parity_frame = None
+    if rank == 0 and world == 1 and part_world == 1 and not args.no_cpu_baseline and not args.no_parity_check:
+        parity_frame = scene.resolve()   # (rgb, bgr8) of the frame the timed region finished: host copies, outside the clock
+    # The same steps with the reference's walk, outside the timed region (one warm-up step, two timed): what the early exits are
+    # worth, and the V / T per ray of the REFERENCE traversal that SURVEY 8(d)'s algorithmic bytes are defined by.
+    ref_walk = None
+    if rank == 0 and world == 1 and walk == _abi.WALK_EARLY_EXIT and not args.no_extras:
+        rp = type(params).from_buffer_copy(params)
+        rp.walk = _abi.WALK_REFERENCE
+        rp.spp = spp_step * 3
+        scene.begin(rp)
+        rw = _abi.Stats()
+        scene.step(spp_step, rw)
+        rs = _abi.Stats()
+        torch.cuda.synchronize()
+        r0 = time.perf_counter()
+        scene.step(spp_step, rs)
+        scene.step(spp_step, rs)
+        rdt = time.perf_counter() - r0
+        scene.flush(None)
+        r_rays = float(rs.rays_primary + rs.rays_secondary)
+        r_trace = max(float(r_rays - rs.rays_inline), 1.0)
+        ref_walk = {"value": r_rays / rdt / 1e6, "unit": "Mray/s", "ms_per_step": rdt / 2 * 1e3, "steps": 2, "warmup": 1,
+                    "k_trace_ms_per_step": rs.trace_ms / 2, "k_trace_Mray_per_s": r_trace / (rs.trace_ms * 1e-3) / 1e6 if rs.trace_ms else None,
+                    "nodes_per_ray_k_trace": float(rs.nodes_visited - rs.nodes_inline) / r_trace,
+                    "tris_per_ray_k_trace": float(rs.tris_tested - rs.tris_inline) / r_trace,
+                    "what": "this rank's share of the frame, same steps, jade_render_params.walk = JADE_WALK_REFERENCE (nodes_visited / tris_tested "
+                            "equal the oracle's); outside the timed region"}
+
     if rank == 0:
         # rooflines of the dominant kernel (k_trace) on THIS rank
         # k_trace traces what the fused first-pass kernel (k_light: camera rays, floor mirrors) did not trace itself
         rays_rank = float(st.rays_primary + st.rays_secondary - st.rays_inline)
-        v_trace, t_trace = float(st.nodes_visited - st.nodes_inline), float(st.tris_tested - st.tris_inline)
-        alg_trace = 40.0 * v_trace + 36.0 * t_trace          # bytes the reference traversal needs for k_trace's rays
+        v_trace, t_trace = float(st.nodes_visited - st.nodes_inline), float(st.tris_tested - st.tris_inline)   # node records read / triangle tests made
+        # bytes the REFERENCE traversal needs for k_trace's rays - with early exits the kernel reads fewer, so V and T
+        # per ray come from the reference-walk steps above (the same rays: the frame is the same)
+        if ref_walk is not None:
+            alg_trace = (40.0 * ref_walk["nodes_per_ray_k_trace"] + 36.0 * ref_walk["tris_per_ray_k_trace"]) * rays_rank
+        else:
+            alg_trace = 40.0 * v_trace + 36.0 * t_trace
         alg_light = 40.0 * st.nodes_inline + 36.0 * st.tris_inline
         launches = max(int(st.trace_launches), 1)
         trace_s = st.trace_ms * 1e-3
@@ -322,7 +360,10 @@ def main():
                             f"{spp_step} spp per step, tiles dealt over {world} GPU(s)",
                 "spp_per_step": spp_step, "width": width, "height": height, "triangles": hs.n_triangles,
                 "bvh_nodes": hs.n_nodes, "bvh_depth": hs.bvh_depth, "parallelism": f"tiles{world}",
+                "walk": "reference" if args.reference_walk else "early_exit",
             },
+            # the same steps with every query walked to the end as the reference does (null with --reference-walk / --no-extras)
+            "reference_walk": ref_walk,
             "virtual_ranks": part_world if part_world != world else None,
             "rehearsal_all_ranks_on_one_gpu": True if rehearsal else None,
             "rays": rays_all,
@@ -339,8 +380,8 @@ def main():
                                     "algorithmic_GBps": alg_light / (st.light_ms * 1e-3) / 1e9 if st.light_ms else None},
                         "k_trace": {"ms_per_step": st.trace_ms / max(args.steps, 1), "rays": rays_rank,
                                     "Mray_per_s": rays_rank / trace_s / 1e6 if trace_s > 0 else None,
-                                    "nodes_per_ray": v_trace / max(rays_rank, 1.0), "tris_per_ray": t_trace / max(rays_rank, 1.0),
-                                    "algorithmic_bytes_per_ray": alg_trace / max(rays_rank, 1.0),
+                                    "nodes_per_ray": v_trace / max(rays_rank, 1.0), "tris_per_ray": t_trace / max(rays_rank, 1.0),   # read / made by this walk
+                                    "algorithmic_bytes_per_ray": alg_trace / max(rays_rank, 1.0),                                   # of the reference's walk
                                     "algorithmic_GBps": alg_trace / trace_s / 1e9 if trace_s > 0 else None},
                         "device_ms_per_step": st.kernel_ms / max(args.steps, 1),
                         "rest_ms_per_step": (st.kernel_ms - st.trace_ms - st.light_ms) / max(args.steps, 1)},
@@ -363,11 +404,8 @@ def main():
             # the resource with the largest share of its roof (null when the counter file belongs to another build)
             "binding": roof["bound"] if roof.get("frac") is not None else None,
         }
-        parity_frame = None
-        if world == 1 and part_world == 1 and not args.no_cpu_baseline and not args.no_parity_check:
-            parity_frame = scene.resolve()   # (rgb, bgr8) of the frame the timed region finished: host copies, outside the clock
         if world == 1 and part_world == 1 and not args.no_extras and args.config in ("C2", "C3", "C4"):
-            out["statue_closeup"] = closeup(scene, hip, B, H, _abi, cfg, width, height, args.spp_per_step)
+            out["statue_closeup"] = closeup(scene, hip, B, H, _abi, cfg, width, height, args.spp_per_step, walk)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(hs, cfg, width, height, args.cpu_spp)
             if parity_frame is not None:
@@ -378,7 +416,7 @@ def main():
         dist.destroy_process_group()
 
 
-def closeup(scene, hip, B, H, _abi, cfg, width, height, spp):
+def closeup(scene, hip, B, H, _abi, cfg, width, height, spp, walk):
     """The same scene with the camera moved in until the statue fills the frame: every pixel starts a jade path
     (BSSRDF / SSS / mirror branches, ~4 shadow + environment + indirect rays per bounce).  The headline frame is
     ~5 % statue; this is the rate on the rays it has few of.  One warm-up step, one timed step, both flushed."""
@@ -388,7 +426,7 @@ def closeup(scene, hip, B, H, _abi, cfg, width, height, spp):
     forward = -np.array(cfg.camera[8:11], np.float32)                       # the view axis: M . (0, 0, -1, 0)
     eye = centre - 0.22 * forward                                           # C3 looks at it from 0.56 away
     spp = max(1, min(spp, 256))
-    p = B.make_params(width, height, spp, [float(x) for x in eye], list(cfg.camera))
+    p = B.make_params(width, height, spp, [float(x) for x in eye], list(cfg.camera), walk=walk)
     scene.begin(p)
     w = _abi.Stats()
     scene.step(spp, w)

@@ -34,7 +34,7 @@ extern "C" {
 
 /* bump whenever a struct layout or a documented semantic changes; callers compare
  * jade_abi_version() with the value they were compiled against */
-#define JADE_ABI_VERSION 5
+#define JADE_ABI_VERSION 6
 
 /* status codes */
 #define JADE_OK 0
@@ -148,7 +148,22 @@ typedef struct jade_render_params {
    * small; a progressive host that will add many samples per step passes that number in `spp` here.
    * The image does not depend on either.  Oracle: ignored. */
   uint64_t max_state_bytes;
+  /* How a hitBVH query (PathTrace.cu:795-859) is answered - JADE_WALK_*.  The reference walks every node whose box the
+   * ray meets and keeps the nearest hit, whatever the caller then does with it.  Two of its three kinds of secondary
+   * query only ask a yes/no question of that hit: a shadow ray (:956, 1096, 1292) is used as "is the nearest hit the
+   * emitter it aims at" (:957, 1097, 1293), an environment-visibility ray (:980, 1123, 1316) as "is there any hit"
+   * (:981, 1124, 1317).  JADE_WALK_EARLY_EXIT ends such a walk at the first recorded hit that settles the question -
+   * any hit for the environment ray; for the shadow ray a hit strictly nearer than the emitter's own hitTriangle
+   * distance, computed up front with the same statements - so the answer, and with it every sample, pixel and ray
+   * count, is the reference's bit for bit (nothing is judged by a tolerance; no box is left out by distance), while
+   * nodes_visited / tris_tested count what was actually read and are smaller.  JADE_WALK_REFERENCE (0, what a
+   * zero-filled struct asks for) visits what the reference visits: nodes_visited / tris_tested equal the oracle's.
+   * Oracle: ignored (it is the reference walk). */
+  int32_t walk;
+  int32_t reserved0;     /* 0 */
 } jade_render_params;
+#define JADE_WALK_REFERENCE 0
+#define JADE_WALK_EARLY_EXIT 1
 
 /* Exact integer work counters; the oracle's and the HIP module's must be
  * equal for the same inputs.  One "ray" is one hitBVH query

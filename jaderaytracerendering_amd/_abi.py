@@ -6,7 +6,7 @@ reference device structs, PathTrace.cu:327-351).
 """
 import ctypes as C
 
-JADE_ABI_VERSION = 5
+JADE_ABI_VERSION = 6
 JADE_SAMPLE_LANES = 1024
 JADE_OK, JADE_ERR_INVALID, JADE_ERR_DEVICE, JADE_ERR_NOMEM, JADE_ERR_UNSUPPORTED = range(5)
 DIFFUSE, MIRROR = 0, 1
@@ -14,6 +14,7 @@ NO_REFRACT, SUB_SURFACE, DIR_REFRACT = 0, 1, 2
 TILE_SIZE = 16
 TONEMAP_ACES, TONEMAP_REINHARD = 0, 1
 Q_RECORDS_PER_PIXEL, Q_STATE_BYTES, Q_SUM_LANES = 0, 1, 2
+WALK_REFERENCE, WALK_EARLY_EXIT = 0, 1
 
 f3 = C.c_float * 3
 f16 = C.c_float * 16
@@ -60,6 +61,8 @@ class RenderParams(C.Structure):
         ("tile_rank", C.c_int32), ("tile_nranks", C.c_int32),
         ("device_id", C.c_int32), ("threads", C.c_int32),
         ("max_state_bytes", C.c_uint64),
+        ("walk", C.c_int32),
+        ("reserved0", C.c_int32),
     ]
 
 

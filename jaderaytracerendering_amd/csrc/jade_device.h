@@ -149,6 +149,13 @@ struct PathState {
   // out, nslots results back) is one or two cache lines for k_shade - as planes (round 1) it was a line per component:
   // 28 lines per record and pass once the active list had thinned out.  A queue entry is the slot number p * nslots + k.
   float4* slot;
+  // jade_render_params.walk == JADE_WALK_EARLY_EXIT: k_trace ends a shadow / environment-visibility walk at the first recorded
+  // hit that settles what k_shade asks of it.  The word a queued ray carries beside its direction (slot[..].w, overwritten by
+  // the result) is the LIMIT as a float: the walk may end once its best distance is < limit.  -1 (a NaN: never) = the nearest
+  // hit is wanted; JADE_INF_F = any recorded hit (hitArray records a hit only below INF, PathTrace.cu:787); a shadow ray carries
+  // the distance at which hitTriangle meets the emitter it aims at (JADE_INF_F if it does not: then no hit can make it
+  // visible).  -2 (also a NaN) = no ray in this slot.  With the reference walk k_trace ignores the word.
+  uint32_t early_exit;
 };
 
 enum : uint32_t {

@@ -414,7 +414,7 @@ static __device__ __forceinline__ void shade_tail(const PathState& P, int p, uin
     for (int i = 0; i < w; ++i) wbase += sh_rays[i];
     const int used = !live ? 0 : (st == ST_DIFFUSE || st == ST_BSSRDF) ? P.nslots : 1;
     for (int k = 0; k < P.nslots; ++k) {
-      const bool q = k < used && reinterpret_cast<const int*>(P.slot + ((size_t)p * P.nslots + k) * 2)[3] == -1;
+      const bool q = k < used && reinterpret_cast<const int*>(P.slot + ((size_t)p * P.nslots + k) * 2)[3] != -2;  // (-2: no ray in this slot; anything else: the queued ray's limit, jade_device.h)
       const unsigned long long m = __ballot(q);
       if (q) queue[wbase + (uint32_t)__popcll(m & below)] = (uint32_t)p * (uint32_t)P.nslots + (uint32_t)k;
       wbase += (uint32_t)__popcll(m);
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
           const jvec3 o = skip == JADE_SKIP_CAMERA ? jv(P.eye[0], P.eye[1], P.eye[2]) : jv(og.x, og.y, og.z);
           const float4 dv = nt_ld4(&P.slot[(size_t)my_e * 2]);
           const jvec3 d = jv(dv.x, dv.y, dv.z);
-          walk_begin(r, stk, S, o, d, skip);
+          walk_begin(r, stk, S, o, d, skip, P.early_exit ? dv.w : __int_as_float(-1));
           active = true;
         }
         V += take;  // the root record of every ray started
@@ -1961,6 +1961,7 @@ int jade_render_begin(jade_scene* s, const jade_render_params* rp) {
   if (!s || !rp) return fail(JADE_ERR_INVALID, "null argument");
   if (rp->width <= 0 || rp->height <= 0 || rp->tile_nranks <= 0 || rp->tile_rank < 0 || rp->tile_rank >= rp->tile_nranks)
     return fail(JADE_ERR_INVALID, "bad image size or tile partition");
+  if (rp->walk != JADE_WALK_REFERENCE && rp->walk != JADE_WALK_EARLY_EXIT) return fail(JADE_ERR_INVALID, "unknown walk (JADE_WALK_*)");
   HIP_TRY(hipSetDevice(s->device));
   const int tx = (rp->width + JADE_TILE_SIZE - 1) / JADE_TILE_SIZE, ty = (rp->height + JADE_TILE_SIZE - 1) / JADE_TILE_SIZE;
   s->tile_ids.clear();
@@ -2023,6 +2024,7 @@ int jade_render_begin(jade_scene* s, const jade_render_params* rp) {
   if (npix64 == 0) { s->ps.npix = 0; s->ps.npx = 0; s->have_rp = true; return JADE_OK; }
   int rc = setup_state(s, (int)npx64, rpp, nslots, sum_lanes);
   if (rc) return rc;
+  s->ps.early_exit = rp->walk == JADE_WALK_EARLY_EXIT ? 1u : 0u;
   memcpy(s->ps.eye, rp->eye, sizeof s->ps.eye);
   HIP_TRY(upload(s->b_tiles, s->tile_ids.data(), s->tile_ids.size(), s->stream));
   HIP_TRY(hipMemsetAsync(s->b_ctr.p, 0, sizeof(DevCounters) * JADE_CTR_SHARDS, s->stream));
@@ -2659,8 +2661,10 @@ int jade_render_multi(jade_scene* const* scenes, int ndev, const jade_render_par
   return JADE_OK;
 }
 
-int jade_trace_rays(jade_scene* s, int32_t n, const float* origins, const float* dirs, const int32_t* skip, int32_t* hit_index,
-                    float* hit_dist, float* hit_point, jade_stats* st) {
+// limits (nullable): per ray, the distance below which a recorded hit ends the walk (JADE_WALK_EARLY_EXIT as k_shade asks
+// for it, jade_device.h); null = the reference's walk
+static int trace_rays_impl(jade_scene* s, int32_t n, const float* origins, const float* dirs, const int32_t* skip, const float* limits,
+                           int32_t* hit_index, float* hit_dist, float* hit_point, jade_stats* st) {
   if (!s || n < 0 || !origins || !dirs || !skip || !hit_index) return fail(JADE_ERR_INVALID, "null argument");
   if (n == 0) return JADE_OK;
   HIP_TRY(hipSetDevice(s->device));
@@ -2674,7 +2678,7 @@ int jade_trace_rays(jade_scene* s, int32_t n, const float* origins, const float*
     memcpy(&skf, &sk, 4);
     memcpy(&qf, &queued, 4);
     so[i] = make_float4(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2], skf);
-    sl[2 * i] = make_float4(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], qf);
+    sl[2 * i] = make_float4(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], limits ? limits[i] : qf);
     sl[2 * i + 1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // the hit point of a miss is reported as zeros
   }
   std::vector<uint32_t> q(N);
@@ -2689,6 +2693,7 @@ int jade_trace_rays(jade_scene* s, int32_t n, const float* origins, const float*
   P.nslots = 1;
   P.orgs = b_orgs.as<float4>();
   P.slot = b_slot.as<float4>();
+  P.early_exit = limits ? 1u : 0u;
   // everything on the scene's own (non-blocking) stream: the null stream does not order against it
   QueueCtl qc{};
   qc.count = (uint32_t)n;
@@ -2728,6 +2733,45 @@ int jade_trace_rays(jade_scene* s, int32_t n, const float* origins, const float*
     st->trace_ms += ms;
     st->trace_launches += 1;
   }
+  return JADE_OK;
+}
+
+int jade_trace_rays(jade_scene* s, int32_t n, const float* origins, const float* dirs, const int32_t* skip, int32_t* hit_index,
+                    float* hit_dist, float* hit_point, jade_stats* st) {
+  return trace_rays_impl(s, n, origins, dirs, skip, nullptr, hit_index, hit_dist, hit_point, st);
+}
+
+// Development / tests (not part of jade_rt.h): jade_trace_rays with a limit per ray - k_trace's early exit on its own, outside
+// the integrator.  For a ray whose nearest hit is not nearer than its limit the answer is the reference's; otherwise it is SOME
+// recorded hit nearer than the limit (which one depends on the schedule of the wave).
+int jade_debug_trace_rays_limit(jade_scene* s, int32_t n, const float* origins, const float* dirs, const int32_t* skip, const float* limits,
+                                int32_t* hit_index, float* hit_dist, float* hit_point, jade_stats* st) {
+  if (!limits) return fail(JADE_ERR_INVALID, "null argument");
+  return trace_rays_impl(s, n, origins, dirs, skip, limits, hit_index, hit_dist, hit_point, st);
+}
+
+// Development / tests (not part of jade_rt.h): shadow_limit (jade_shade.h) for n rays against triangle tri (BVH order): what
+// k_shade writes beside a shadow ray's direction.
+__global__ void k_debug_shadow_limit(DevScene S, int n, const float* o, const float* d, const int32_t* tri, float* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = shadow_limit(&S.tris[tri[i]], jv(o[3 * i], o[3 * i + 1], o[3 * i + 2]), jv(d[3 * i], d[3 * i + 1], d[3 * i + 2]));
+}
+int jade_debug_shadow_limit(jade_scene* s, int32_t n, const float* origins, const float* dirs, const int32_t* tri, float* limit) {
+  if (!s || n <= 0 || !origins || !dirs || !tri || !limit) return fail(JADE_ERR_INVALID, "null argument");
+  for (int i = 0; i < n; ++i)
+    if (tri[i] < 0 || tri[i] >= s->dev.n_tris) return fail(JADE_ERR_INVALID, "triangle index out of range");
+  HIP_TRY(hipSetDevice(s->device));
+  const size_t N = (size_t)n;
+  DevBuf bo, bd, bt, bl;
+  HIP_TRY(upload(bo, origins, 3 * N, s->stream));
+  HIP_TRY(upload(bd, dirs, 3 * N, s->stream));
+  HIP_TRY(upload(bt, tri, N, s->stream));
+  HIP_TRY(bl.alloc(N * 4));
+  hipLaunchKernelGGL(k_debug_shadow_limit, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s->stream, s->dev, n, bo.as<float>(), bd.as<float>(),
+                     bt.as<int32_t>(), bl.as<float>());
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(limit, bl.p, N * 4, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
   return JADE_OK;
 }
 

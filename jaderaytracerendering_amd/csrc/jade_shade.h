@@ -79,6 +79,30 @@ static __device__ __forceinline__ float tri_size(const jade_triangle* t) {  // P
   return 0.5f * jade_sqrt(jv_dot(cp, cp));
 }
 
+// The LIMIT a shadow ray carries to k_trace (jade_device.h, PathState.early_exit): hitTriangle (PathTrace.cu:705-754) of the ray
+// with the emitter it aims at, statement for statement as the walk's own test evaluates it (jade_trace.h pair_core / tri_hit: the
+// same helpers, so the same bits - test_gpu_early_exit.py compares them) - the distance if HitResult.isHit and hitArray would
+// record it (distance < INF, :787), else JADE_INF_F: hitBVH can then not return this emitter, and any hit settles the query.
+// The caller's use of the query (:957, 1097, 1293) is "isHit && index == emitter": true iff no triangle of the walk is recorded
+// before the emitter with a distance <= its own, so a recorded hit STRICTLY nearer than this value makes it false for good.
+static __device__ float shadow_limit(const jade_triangle* t, jvec3 o, jvec3 d) {
+  const jvec3 p1 = V3(t->p1), p2 = V3(t->p2), p3 = V3(t->p3);
+  const jvec3 dn = jv_normalize(d);
+  const jvec3 sa = jv_sub(p1, jv_scale(dn, jv_dot(dn, jv_sub(p1, o))));
+  const jvec3 sb = jv_sub(p2, jv_scale(dn, jv_dot(dn, jv_sub(p2, o))));
+  const jvec3 sc = jv_sub(p3, jv_scale(dn, jv_dot(dn, jv_sub(p3, o))));
+  const jvec3 pa = jv_sub(sa, o), pb = jv_sub(sb, o), pc = jv_sub(sc, o);
+  const float papb = jv_mixed(dn, pa, pb), pbpc = jv_mixed(dn, pb, pc), pcpa = jv_mixed(dn, pc, pa);
+  if (!((papb > 0 && pbpc > 0 && pcpa > 0) || (papb < 0 && pbpc < 0 && pcpa < 0))) return JADE_INF_F;
+  const jvec3 eb = jv_sub(sb, sa), ec = jv_sub(sc, sa), q = jv_sub(o, sa);
+  const float divider = jade_diffprod(eb.x, ec.y, eb.y, ec.x);
+  const float rate_a = jade_diffprod(ec.y, q.x, ec.x, q.y) / divider;
+  const float rate_b = jade_fma(eb.x, q.y, (-eb.y) * q.x) / divider;
+  const jvec3 P = jv_add(jv_add(p1, jv_scale(jv_sub(p2, p1), rate_a)), jv_scale(jv_sub(p3, p1), rate_b));
+  const float distance = jv_dot(jv_sub(P, o), dn);
+  return (distance > 0 && distance < JADE_INF_F) ? distance : JADE_INF_F;
+}
+
 // a triangle as shading sees it: its flat normal and its object's material (jade_device.h, DevMaterial)
 struct ShadeTri {
   jvec3 norm;
@@ -137,6 +161,7 @@ struct Px {
   }
   __device__ int hit(int k) const { return reinterpret_cast<const int*>(slot(k))[3]; }
   __device__ void set_hit(int k, int v) const { reinterpret_cast<int*>(slot(k))[3] = v; }
+  __device__ void set_limit(int k, float v) const { reinterpret_cast<float*>(slot(k))[3] = v; }  // a queued ray that may end early (jade_device.h)
   // origin shared by the record's pending rays + the triangle they leave: one float4
   __device__ void set_origin(jvec3 o, int skip) const { P.orgs[p] = make_float4(o.x, o.y, o.z, __int_as_float(skip)); }
   __device__ jvec3 origin() const {
@@ -336,16 +361,18 @@ static __device__ bool begin_bounce(const DevScene& S, const Px& px, ShadeCtx& c
           rx = 1 - rx;
           ry = 1 - ry;
         }
-        jvec3 random_emit_point = tri_point(&T[S.emit[i]], rx, ry);
-        px.set_dir(i, jv_sub(random_emit_point, random_point));
-        px.set_hit(i, -1);
+        const jade_triangle* et = &T[S.emit[i]];
+        jvec3 random_emit_point = tri_point(et, rx, ry);
+        const jvec3 sd = jv_sub(random_emit_point, random_point);
+        px.set_dir(i, sd);
+        px.set_limit(i, shadow_limit(et, random_point, sd));
         c.n_emit_rays++;
       }
       {
         jvec3 ray_direction = sphere_dir(&c.rng);
         if (jv_dot(ray_direction, t_norm) * jv_dot(inner_direction, t_norm) < 0) ray_direction = jv_neg(ray_direction);
         px.set_dir(nE, ray_direction);
-        px.set_hit(nE, -1);
+        px.set_limit(nE, JADE_INF_F);  // environment visibility: any recorded hit
         c.n_emit_rays++;
       }
       jvec3 ray_direction = sphere_dir(&c.rng);
@@ -404,13 +431,14 @@ diffuse_like:
         rand_x = 1 - rand_x;
         rand_y = 1 - rand_y;
       }
-      jvec3 random_point = tri_point(&T[S.emit[i]], rand_x, rand_y);
+      const jade_triangle* et = &T[S.emit[i]];
+      jvec3 random_point = tri_point(et, rand_x, rand_y);
       jvec3 obj_light_direction = jv_sub(random_point, c.src);
       px.set_dir(i, obj_light_direction);
       if (jv_dot(obj_light_direction, n) * side < 0) {
         px.set_hit(i, -2);  // `continue`: no shadow ray
       } else {
-        px.set_hit(i, -1);
+        px.set_limit(i, shadow_limit(et, c.src, obj_light_direction));
         c.n_emit_rays++;
       }
     }
@@ -418,7 +446,7 @@ diffuse_like:
       jvec3 ray_direction = sphere_dir(&c.rng);
       if (jv_dot(ray_direction, n) * side < 0) ray_direction = jv_neg(ray_direction);
       px.set_dir(nE, ray_direction);
-      px.set_hit(nE, -1);
+      px.set_limit(nE, JADE_INF_F);  // environment visibility: any recorded hit
       c.n_emit_rays++;
     }
     float rr_result = jade_rand(&c.rng);

@@ -602,7 +602,7 @@ static __device__ __forceinline__ void ray_step_tri_s(RayState& r, const DevScen
 // A lane's column: the stack, the best hit {distance, sequence, record | A/B}, the finished-leaf counter, a dummy (1/d is
 // in registers: the kernel runs 4 waves per SIMD and has them to spare).
 // ---------------------------------------------------------------------------------------------------------------
-enum { TW_BEST_DIST = JADE_LDS_STACK, TW_BEST_SEQ, TW_BEST_REF, TW_FINISHED, TW_DUMMY, TW_END };
+enum { TW_BEST_DIST = JADE_LDS_STACK, TW_BEST_SEQ, TW_BEST_REF, TW_FINISHED, TW_DUMMY, TW_LIMIT, TW_END };
 #ifndef JADE_WQ
 #define JADE_WQ 128 /* items a wave's ring holds (a power of two, >= 128: a walk unit may push 64) */
 #endif
@@ -612,12 +612,14 @@ static_assert((JADE_WQ & (JADE_WQ - 1)) == 0 && JADE_WQ >= 128, "JADE_WQ");
 #endif
 static_assert((JADE_HQ & (JADE_HQ - 1)) == 0 && JADE_HQ >= 128, "JADE_HQ");
 #ifndef JADE_HQ_BATCH
-#define JADE_HQ_BATCH 64 /* candidates waiting that trigger a resolve pass */
+#define JADE_HQ_BATCH 32 /* candidates waiting that trigger a resolve pass.  With early exits (round 3) a ray learns that it has its answer when its candidates are resolved: 64 / 32 / 16 = 127.6 / 121.0 / 121.2 ms of k_trace per 256-spp step of C3, 912 / 869 / 873 on the close-up (reference walk, round 2: 64 was best by 1-3 %) */
 #endif
 
 #ifndef JADE_PREFETCH
 #define JADE_PREFETCH 0 /* 1: a walk unit ends by requesting the record of the node the walk goes to next (WalkState.pre), so that its latency passes while the wave pushes leaves, picks its next kind of work, tests triangles */
 #endif
+#define JADE_CUT 0x40000000u       /* WalkState.skipx: the ray has its answer (early exit) */
+#define JADE_SKIP_MASK 0x3fffffffu /* ... its source triangle (all ones = none; triangle indices stay below 2^27) */
 struct WalkState {
 #if JADE_PREFETCH
   NodeRec pre;      // the record of `cur`, requested when cur was set
@@ -632,14 +634,16 @@ struct WalkState {
 static __device__ __forceinline__ void lds_st_v(uint32_t addr, uint32_t v) { *(volatile jade_lds_u32*)(__SIZE_TYPE__)addr = v; }
 static __device__ __forceinline__ uint32_t lds_ld_v(uint32_t addr) { return *(volatile jade_lds_u32*)(__SIZE_TYPE__)addr; }
 
-static __device__ __forceinline__ void walk_begin(WalkState& r, const LdsStack& stk, const DevScene& S, jvec3 o, jvec3 d, int32_t skip) {
+// limit: the walk may end as soon as the ray's best distance is < limit (jade_device.h, PathState.early_exit; a NaN = never:
+// the nearest hit is wanted and the walk is the reference's)
+static __device__ __forceinline__ void walk_begin(WalkState& r, const LdsStack& stk, const DevScene& S, jvec3 o, jvec3 d, int32_t skip, float limit) {
   const jvec3 inv = jv(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
   const jvec3 dn = jv_normalize(d);
   r.od.a = f2{o.x, o.y};
   r.od.b = f2{o.z, dn.x};
   r.od.c = f2{dn.y, dn.z};
   const bool exact = !(finite_f(inv.x) && finite_f(inv.y) && finite_f(inv.z)) || !finite_f(o.x) || !finite_f(o.y) || !finite_f(o.z);
-  r.skipx = (skip < 0 ? 0x7fffffffu : (uint32_t)skip) | (exact ? 0x80000000u : 0u);
+  r.skipx = (skip < 0 ? JADE_SKIP_MASK : (uint32_t)skip) | (exact ? 0x80000000u : 0u);
   r.sp = stk.col;
   r.pushed = 0;
   r.cur = S.root_ref;
@@ -648,6 +652,7 @@ static __device__ __forceinline__ void walk_begin(WalkState& r, const LdsStack& 
   lds_put(stk, TW_BEST_SEQ, 0xffffffffu);
   lds_put(stk, TW_BEST_REF, 0xffffffffu);
   lds_st_v(stk.col + TW_FINISHED * JADE_COL_STRIDE, 0u);
+  lds_putf(stk, TW_LIMIT, limit);
 #if JADE_PREFETCH
   r.pre = node_fetch<JADE_TRACE_TOP_NODES>(r.cur, S, stk);
 #endif
@@ -668,15 +673,21 @@ static __device__ __forceinline__ uint32_t walk_step(WalkState& r, const DevScen
 // owner lane | sequence << 6, od / skip = the owner's ray (the caller's ds_bpermute), rec = the record (the caller's
 // pair_load, issued before the ds_bpermutes so that the two latencies overlap), lane = this lane.  in_a / in_b: the origin
 // projects into triangle A / B of the record - a candidate the caller queues (resolve_hit).
-static __device__ __forceinline__ void test_step(uint32_t& item_leaf, uint32_t meta, const RayOD& od, uint32_t skip, const PairRec& rec, const LdsStack& stk,
-                                                 int lane, uint32_t& tcnt, bool& in_a, bool& in_b) {
+// cut: the owner's ray already has its answer (early exit) - the rest of the leaf is dropped untested.
+static __device__ __forceinline__ void test_step(uint32_t& item_leaf, uint32_t meta, const RayOD& od, uint32_t skip, bool cut, const PairRec& rec,
+                                                 const LdsStack& stk, int lane, uint32_t& tcnt, bool& in_a, bool& in_b) {
   const uint32_t leaf = item_leaf + 79u;  // next pair record (5 x 16 B), one pair fewer
   uint32_t idx_a;
+  const uint32_t tcnt0 = tcnt;
   pair_core(od, skip, rec, tcnt, in_a, in_b, idx_a);
+  if (cut) {
+    tcnt = tcnt0;
+    in_a = in_b = false;
+  }
   const uint32_t ocol = stk.col + ((meta & 63u) - (uint32_t)lane) * 4u;  // the owner's column
   // the ray must not end before its candidates are resolved: each takes one off the finished-leaf count until then
   const uint32_t n_cand = (in_a ? 1u : 0u) + (in_b ? 1u : 0u);
-  const bool fin = (leaf & 15u) == 0;
+  const bool fin = cut || (leaf & 15u) == 0;
   const uint32_t delta = (fin ? 1u : 0u) - n_cand;
   if (delta != 0u)
     __hip_atomic_fetch_add((jade_lds_u32*)(__SIZE_TYPE__)(ocol + TW_FINISHED * JADE_COL_STRIDE), delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -783,7 +794,7 @@ struct WaveTrace {
     return od;
   }
   // resolve up to 64 of the waiting candidates, one per lane
-  __device__ __forceinline__ void resolve_pass(const WalkState& r, const DevScene& S, const LdsStack& stk) {
+  __device__ __forceinline__ void resolve_pass(WalkState& r, const DevScene& S, const LdsStack& stk) {
     const uint32_t nres = h_count < 64u ? h_count : 64u;
     const bool mine = (uint32_t)lane < nres;
     uint32_t ref = 0, meta = 0;
@@ -792,6 +803,14 @@ struct WaveTrace {
     h_count -= nres;
     const RayOD od = ray_of(r, (int)(meta & 63u));
     if (mine) resolve_hit(ref, meta, od, S, stk, lane);
+    // Early exit (JADE_WALK_EARLY_EXIT): a ray whose best hit is now nearer than its limit has its answer - its walk ends
+    // here (stack dropped) and the leaves it has pushed but that no lane has taken yet are dropped unread (JADE_CUT in
+    // skipx, seen by whoever takes one).  A lane without a ray has cur == NONE and sp at its base already.
+    if (lds_getf(stk, TW_BEST_DIST) < lds_getf(stk, TW_LIMIT)) {
+      r.cur = JADE_REF_NONE;
+      r.sp = stk.col;
+      r.skipx |= JADE_CUT;
+    }
   }
   // a lane's ray has ended: its walk has, and every leaf it pushed has been finished (candidates included)
   static __device__ __forceinline__ bool ray_ended(const WalkState& r, const LdsStack& stk) {
@@ -910,11 +929,12 @@ struct WaveTrace {
         PROF_LAP(pr, PL_TEST_LOAD);
         const int owner = (int)(item_meta & 63u);
         const RayOD od = ray_of(r, owner);
-        const uint32_t skip = (uint32_t)__shfl((int)r.skipx, owner, 64) & 0x7fffffffu;
+        const uint32_t sx = (uint32_t)__shfl((int)r.skipx, owner, 64);
+        const uint32_t skip = sx & JADE_SKIP_MASK;
         PROF_DRAIN();
         PROF_LAP(pr, PL_TEST_RAY);
         bool in_a = false, in_b = false;
-        if (go) test_step(item_leaf, item_meta, od, skip, rec, stk, lane, tcnt, in_a, in_b);
+        if (go) test_step(item_leaf, item_meta, od, skip, (sx & JADE_CUT) != 0u, rec, stk, lane, tcnt, in_a, in_b);
         PROF_DRAIN();
         PROF_LAP(pr, PL_TEST_MATH);
         // candidates (the origin projects into the triangle) are resolved later, many at a time

@@ -201,8 +201,90 @@ static void hist_add(int which, uint64_t v) {
   __sync_fetch_and_add(&g_visit_hist[which][b], 1);
 }
 
+/* Diagnostics only (not part of jade_rt.h, and NOT the reference's algorithm): a walk that leaves out children whose box
+ * begins farther along the ray than the nearest hit found so far - what SURVEY section 7 step 5 calls "optional distance
+ * pruning".  tools/prune_probe.py uses it to count what such a walk visits and whether the frame keeps its bits; the
+ * checker the parity tests use is hit_bvh below, untouched.  mode 1: a child is judged when its parent is visited;
+ * mode 2: and again when it is popped. */
+static int g_prune_mode = 0;
+static float g_prune_rel = 0.0f, g_prune_abs = 0.0f, g_prune_minz = 0.0f;
+static uint64_t g_prune_ctr[4]; /* internal nodes popped, leaves popped, triangles tested, calls */
+void jade_oracle_set_prune(int mode, float rel, float abs_, float min_dz) {
+  g_prune_mode = mode; g_prune_rel = rel; g_prune_abs = abs_; g_prune_minz = min_dz;
+}
+void jade_oracle_prune_counters(uint64_t* out, int reset) {
+  memcpy(out, g_prune_ctr, sizeof g_prune_ctr);
+  if (reset) memset(g_prune_ctr, 0, sizeof g_prune_ctr);
+}
+static HitResult hit_bvh_pruned(const jade_scene* s, Ray ray, int src_object_idx, counters* c) {
+  HitResult res;
+  res.isHit = 0; res.index = 0; res.distance = INF_F; res.hitPoint = jv(0, 0, 0);
+  int stack[JADE_BVH_STACK_CAPACITY];
+  float entry[JADE_BVH_STACK_CAPACITY];
+  int sp = 0;
+  stack[sp] = 1; entry[sp] = 0; sp++;
+  const float len = sqrtf(jv_dot(ray.direction, ray.direction));
+  jvec3 nd = jv_normalize(ray.direction);
+  int may = fabsf(nd.z) >= g_prune_minz;
+  uint64_t ni = 0, nl = 0, nt0 = c->tris_tested;
+  counters dummy = *c;
+  /* mode >= 3: what kind of ray this is, from the counter its call site has just advanced (a probe's shortcut) */
+  static __thread uint64_t seen_shadow, seen_env;
+  int kind = 0; /* 1 shadow, 2 env */
+  if (c->rays_shadow != seen_shadow) { kind = 1; seen_shadow = c->rays_shadow; }
+  else if (c->rays_env != seen_env) { kind = 2; seen_env = c->rays_env; }
+  float d_e = -1.0f; /* shadow ray: the distance at which it meets the emitter it aims at */
+  if (g_prune_mode >= 3 && kind == 1)
+    for (int i = 0; i < s->d.n_emit; ++i) {
+      HitResult h = hit_triangle(&s->tris[s->emit[i]], ray, s->emit[i]);
+      if (h.isHit && (d_e < 0 || h.distance < d_e)) d_e = h.distance;
+    }
+  if (g_prune_mode == 3) may = 0; /* mode 3: early exits only, nothing judged by distance */
+  while (sp > 0) {
+    if (g_prune_mode >= 3 && res.isHit && (kind == 2 || (kind == 1 && d_e > 0 && res.distance < d_e))) break;
+    --sp;
+    int top = stack[sp];
+    const jade_bvh_node* node = &s->nodes[top];
+    const float limit = res.distance * (1.0f + g_prune_rel) + g_prune_abs;
+    if (g_prune_mode >= 2 && may && entry[sp] * len > limit) continue;
+    if (node->n > 0) {
+      ++nl;
+      HitResult r = hit_array(s, ray, node->index, node->index + node->n - 1, src_object_idx, c);
+      if (r.isHit && r.distance < res.distance) res = r;
+      continue;
+    }
+    ++ni;
+    float d1 = -1, d2 = -1;
+    if (node->left > 0) d1 = hit_aabb(ray, V3(s->nodes[node->left].aa), V3(s->nodes[node->left].bb));
+    if (node->right > 0) d2 = hit_aabb(ray, V3(s->nodes[node->right].aa), V3(s->nodes[node->right].bb));
+    /* the box's entry point along the ray: hit_aabb's value when the origin is outside the box (then it returned t0),
+     * recomputed here to tell the two cases apart */
+    float e1 = 0, e2 = 0;
+    if (d1 > 0) { Ray q = ray; jvec3 inv = jv(1.0f / q.direction.x, 1.0f / q.direction.y, 1.0f / q.direction.z);
+      jvec3 f = jv_mul(jv_sub(V3(s->nodes[node->left].bb), q.startPoint), inv), n = jv_mul(jv_sub(V3(s->nodes[node->left].aa), q.startPoint), inv);
+      jvec3 tm = vmin3(f, n); float t0 = jade_fmaxf(tm.x, jade_fmaxf(tm.y, tm.z)); e1 = t0 > 0 ? t0 : 0; }
+    if (d2 > 0) { Ray q = ray; jvec3 inv = jv(1.0f / q.direction.x, 1.0f / q.direction.y, 1.0f / q.direction.z);
+      jvec3 f = jv_mul(jv_sub(V3(s->nodes[node->right].bb), q.startPoint), inv), n = jv_mul(jv_sub(V3(s->nodes[node->right].aa), q.startPoint), inv);
+      jvec3 tm = vmin3(f, n); float t0 = jade_fmaxf(tm.x, jade_fmaxf(tm.y, tm.z)); e2 = t0 > 0 ? t0 : 0; }
+    if (may && d1 > 0 && e1 * len > limit) d1 = -1;
+    if (may && d2 > 0 && e2 * len > limit) d2 = -1;
+    if (d1 > 0 && d2 > 0) {
+      if (d1 < d2) { stack[sp] = node->right; entry[sp++] = e2; stack[sp] = node->left; entry[sp++] = e1; }
+      else { stack[sp] = node->left; entry[sp++] = e1; stack[sp] = node->right; entry[sp++] = e2; }
+    } else if (d1 > 0) { stack[sp] = node->left; entry[sp++] = e1; }
+    else if (d2 > 0) { stack[sp] = node->right; entry[sp++] = e2; }
+  }
+  (void)dummy;
+  __sync_fetch_and_add(&g_prune_ctr[0], ni);
+  __sync_fetch_and_add(&g_prune_ctr[1], nl);
+  __sync_fetch_and_add(&g_prune_ctr[2], c->tris_tested - nt0);
+  __sync_fetch_and_add(&g_prune_ctr[3], 1);
+  return res;
+}
+
 /* PathTrace.cu:795-859 */
 static HitResult hit_bvh(const jade_scene* s, Ray ray, int src_object_idx, counters* c) {
+  if (g_prune_mode) return hit_bvh_pruned(s, ray, src_object_idx, c); /* (diagnostics, see above: never set by the tests' checker) */
   HitResult res;
   res.isHit = 0;
   res.index = 0;

@@ -9,12 +9,13 @@ K" with K larger than the number of diagonals is one diagonal of tiles: r is cho
 also crosses the mirror floor, the sky and partial tiles at the frame's edges.
 
 Bar: HIP on that same partition - work counters EXACTLY the oracle's, radiance within 1e-4 relative L2, BGR8 within one
-code value; and the full-frame render's pixels on that diagonal bit-identical to the partition render's.
+code value; the full-frame render's pixels on that diagonal bit-identical to the partition render's; and the full frame
+rendered with early exits (what bench.py times by default) bit-identical to the full frame with the reference's walk.
 """
 import numpy as np
 import pytest
 
-from conftest import B, config_scene, counters, object_tiles, rel_l2
+from conftest import B, assert_early_exit_equals_reference_walk, config_scene, counters, object_tiles, rel_l2
 from jaderaytracerendering_amd import _abi
 from jaderaytracerendering_amd.distributed import owned_tile_ids
 from conftest import tile_mask
@@ -59,6 +60,14 @@ def _check(oracle, hip, name, width, height, announced, spp_steps, K, want_rpp=N
             assert st_full.host_syncs * 4 < st_full.trace_launches
         else:        # the ordered ray queue (trees that do not fit the L2): the host follows every pass
             assert st_full.host_syncs >= st_full.trace_launches
+        # ... and what bench.py times by default: the same schedule with early exits (jade_rt.h, JADE_WALK_EARLY_EXIT) - every
+        # float, byte and ray count of the full frame the same, fewer node records and triangle tests
+        early_p = B.make_params(width, height, announced, list(cfg.eye), list(cfg.camera), walk=_abi.WALK_EARLY_EXIT)
+        st_early = _abi.Stats()
+        rgb_e, bgr_e = _steps(sc, early_p, spp_steps, st_early)
+        assert_early_exit_equals_reference_walk((rgb_full, bgr_full, st_full), (rgb_e, bgr_e, st_early))
+        assert st_early.nodes_visited < st_full.nodes_visited
+        del rgb_e, bgr_e
         st_h = _abi.Stats()
         rgb_h, bgr_h = _steps(sc, part_p, spp_steps, st_h)
     with oracle.scene(hs) as so:

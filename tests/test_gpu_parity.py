@@ -13,7 +13,7 @@ The bar (BASELINE.json north_star / SURVEY.md §8c-d):
 import numpy as np
 import pytest
 
-from conftest import B, J, config_scene, counters, rel_l2
+from conftest import B, J, assert_early_exit_equals_reference_walk, config_scene, counters, rel_l2
 from jaderaytracerendering_amd import _abi
 
 pytestmark = pytest.mark.gpu
@@ -21,10 +21,22 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4  # relative L2 on pre-tonemap radiance, from BASELINE.json north_star
 
 
+def _with_walk(params, walk):
+    q = type(params).from_buffer_copy(params)
+    q.walk = walk
+    return q
+
+
 def _render_both(oracle, hip, hs, params):
+    """The frame through the oracle and through the HIP module with the reference's walk (what the callers compare, counters
+    included); and, checked right here for every scene of this file, through the HIP module with early exits
+    (jade_rt.h, JADE_WALK_EARLY_EXIT): the same bits, the same rays, fewer node records and triangle tests."""
+    assert params.walk == _abi.WALK_REFERENCE
+    early = _with_walk(params, _abi.WALK_EARLY_EXIT)
     with oracle.scene(hs) as so, hip.scene(hs) as sh:
         r_o, b_o, st_o = so.render(params)
         r_h, b_h, st_h = sh.render(params)
+        assert_early_exit_equals_reference_walk((r_h, b_h, st_h), sh.render(early))
     return (r_o, b_o, st_o), (r_h, b_h, st_h)
 
 
@@ -215,6 +227,8 @@ def test_result_independent_of_shade_schedule(hip, monkeypatch):
                 monkeypatch.setenv(key, val)
             with hip.scene(hs) as sc:
                 rgb, bgr, st = sc.render(p)
+                early = sc.render(_with_walk(p, _abi.WALK_EARLY_EXIT))  # ... and so must the frame with early exits, in every schedule
+            assert_early_exit_equals_reference_walk((rgb, bgr, st), early)
             if ref is None:
                 ref = (rgb, bgr, counters(st))
             else:
@@ -236,6 +250,8 @@ def test_result_independent_of_ray_ordering(hip, monkeypatch):
             monkeypatch.setenv("JADE_SORT_MIN", "64")
             with hip.scene(hs) as sc:
                 rgb, bgr, st = sc.render(p)
+                early = sc.render(_with_walk(p, _abi.WALK_EARLY_EXIT))
+            assert_early_exit_equals_reference_walk((rgb, bgr, st), early)
             if ref is None:
                 ref = (rgb, bgr, counters(st))
             else:

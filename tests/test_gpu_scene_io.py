@@ -40,9 +40,9 @@ def _read_pfm(path):
     return data
 
 
-def _run(backend, args, env, out, size, spp):
+def _run(backend, args, env, out, size, spp, extra=()):
     r = subprocess.run([EXE, "--args", args, "--env", env, "--width", str(size[0]), "--height", str(size[1]), "--spp", str(spp),
-                        "--backend", backend, "--out", out], capture_output=True, text=True, timeout=600)
+                        "--backend", backend, "--out", out] + list(extra), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-500:]
     stats = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     return stats, r.stdout
@@ -80,10 +80,15 @@ def test_render_args_obj_hdr_scene_hip_vs_oracle(tmp_path):
 
     size, spp = (96, 64), 6
     st_o, _ = _run(ORACLE_LIB, args, hdr, os.path.join(d, "o.pfm"), size, spp)
-    st_h, log = _run(HIP_LIB, args, hdr, os.path.join(d, "h.pfm"), size, spp)
+    st_h, log = _run(HIP_LIB, args, hdr, os.path.join(d, "h.pfm"), size, spp, ["--reference-walk"])
     assert "hip-gfx950" in log
     keys = ("rays_primary", "rays_secondary", "nodes_visited", "tris_tested", "shaded_hits", "samples")
     assert {k: st_h[k] for k in keys} == {k: st_o[k] for k in keys}                      # every decision identical
+    # the CLI's default walk (early exits, jade_rt.h): the same file byte for byte, the same rays, fewer node records and tests
+    st_e, _ = _run(HIP_LIB, args, hdr, os.path.join(d, "e.pfm"), size, spp)
+    assert open(os.path.join(d, "e.pfm"), "rb").read() == open(os.path.join(d, "h.pfm"), "rb").read()
+    assert {k: st_e[k] for k in keys if k not in ("nodes_visited", "tris_tested")} == {k: st_h[k] for k in keys if k not in ("nodes_visited", "tris_tested")}
+    assert st_e["nodes_visited"] < st_h["nodes_visited"] and st_e["tris_tested"] < st_h["tris_tested"]
     assert st_h["samples"] == size[0] * size[1] * spp and st_h["rays_secondary"] > st_h["samples"] // 4
     a, b = _read_pfm(os.path.join(d, "h.pfm")), _read_pfm(os.path.join(d, "o.pfm"))
     assert a.shape == (size[1], size[0], 3) and rel_l2(a, b) <= 1e-4

@@ -3,7 +3,7 @@
 statue filling the frame) with several builds of libjade_hip*.so in ONE process, variants interleaved
 (cdna_hip_programming.md rule 24).  Every variant holds its own path state: the device memory is split between them
 through jade_render_params.max_state_bytes, so the records per pixel are fewer than in a bench run (printed).
-usage: ab_variants.py "" _A _B ...      ("" = libjade_hip.so)"""
+usage: ab_variants.py "" _A _B ...      ("" = libjade_hip.so; a name may end in @0 / @1: jade_render_params.walk, default 1 = early exits)"""
 import os
 import sys
 import time
@@ -26,9 +26,10 @@ names = sys.argv[1:] or [""]
 budget = int(float(os.environ.get("AB_STATE_GB", "230")) * 1e9 / len(names))
 scenes = {}
 for name in names:
-    be = B.Backend(os.path.join(ROOT, "jaderaytracerendering_amd", "lib", "libjade_hip%s.so" % name))
+    libname, _, walk = name.partition("@")
+    be = B.Backend(os.path.join(ROOT, "jaderaytracerendering_amd", "lib", "libjade_hip%s.so" % libname))
     sc = be.scene(hs)
-    p = B.make_params(W, H, 1024, eye, list(cfg.camera))
+    p = B.make_params(W, H, 1024, eye, list(cfg.camera), walk=int(walk or 1))
     p.max_state_bytes = budget
     sc.begin(p)
     sc.step(SPP)
@@ -42,8 +43,9 @@ for rnd in range(ROUNDS):
         sc.step(SPP, st)
         dt = time.perf_counter() - t
         rays_t = st.rays - st.rays_inline
-        r = (st.rays / dt / 1e6, st.trace_ms, st.light_ms, st.kernel_ms, rays_t / max(st.trace_ms, 1e-9) / 1e3)
+        r = (st.rays / dt / 1e6, st.trace_ms, st.light_ms, st.kernel_ms, rays_t / max(st.trace_ms, 1e-9) / 1e3,
+             (st.nodes_visited - st.nodes_inline) / max(rays_t, 1), (st.tris_tested - st.tris_inline) / max(rays_t, 1))
         if name not in best or r[0] > best[name][0]:
             best[name] = r
 for name, r in best.items():
-    print("%-8s Mray/s %6.0f  k_trace %6.1f ms (%5.0f Mray/s)  k_light %6.1f ms  device %6.1f ms" % (name, r[0], r[1], r[4], r[2], r[3]), flush=True)
+    print("%-8s Mray/s %6.0f  k_trace %6.1f ms (%5.0f Mray/s, V/ray %5.1f T/ray %5.1f)  k_light %6.1f ms  device %6.1f ms" % (name, r[0], r[1], r[4], r[5], r[6], r[2], r[3]), flush=True)
