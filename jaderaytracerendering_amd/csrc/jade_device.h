@@ -54,7 +54,7 @@
 #define JADE_TRACE_BLOCK 256
 #endif
 #ifndef JADE_TRACE_TOP_NODES
-#define JADE_TRACE_TOP_NODES 160 /* k_trace's share of the top (<= JADE_LDS_TOP_NODES): 13 KB of columns + 8 KB of rings + 10 KB of nodes = 31 KB per block; 4 blocks per CU (102 VGPRs).  96 nodes (30 KB, 5 blocks): the same speed on C3, 5 % slower on C5; 224: no better */
+#define JADE_TRACE_TOP_NODES 144 /* k_trace's share of the top (<= JADE_LDS_TOP_NODES): 14 KB of columns + 8 KB of rings + 9 KB of nodes = 31 744 B per block, 5 blocks per CU.  With 160 nodes the block is 32 768 B and 5 x that is the CU's 160 KB to the byte - but only 4 were resident (LDS is handed out in granules: 118.1 vs 121.7 ms of k_trace per 256-spp step of C3, 835 vs 869 on the close-up, once the early-exit limit had taken a 14th column word).  Round 2: 96 nodes the same speed on C3, 5 % slower on C5; 224: no better */
 #endif
 #ifndef JADE_LDS_TOP_NODES  /* 0 = no staging (A/B builds); k_light: 21 KB of columns + 10 KB of nodes per block */
 #define JADE_LDS_TOP_NODES 160 /* k_light's; k_trace per 1024-spp step of C3 (round 2, FIFO form): 570 ms without, 552 with 80, 545 with 160 */
