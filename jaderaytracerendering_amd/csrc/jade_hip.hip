@@ -159,10 +159,14 @@ __global__ __launch_bounds__(JADE_ARM_BLOCK) void k_arm(PathState P, uint32_t ta
 // started with are still active.  The paths left are the long ones (jade: ~10 bounces against 1-2 for the sky and the
 // mirror floor): finishing them inside every step means dozens of thin passes per step, whose sparse record accesses
 // waste most of every cache line; carried over, they ride along with the next step's full passes and the thin tail
-// is paid once per render (C3: 364 -> 286 k_trace launches per 4096 spp, +3 % Mray/s at 0.02; 0.07 and 0.2 measure the
-// same).  JADE_CARRY_FRACTION in the environment overrides it (0 = only the absolute floor below).
+// is paid once per render (round 1, C3: 364 -> 286 k_trace launches per 4096 spp, +3 % Mray/s at 0.02 against none).  What
+// is carried is work moved, not saved: the flush at the end of a render finishes it, so the fraction sets how long that
+// flush is - round 3, 4 x 1024 spp of C3 with the flush inside the clock: 0.001 / 0.002 / 0.003 / 0.005 / 0.02 / 0.05 = 708.6 /
+// 707.9 / 705.5 / 705.4 / 709.5 / 698 + 167 ms per step, with a final flush of 32 / 40 / 49 / 67 / 210 / 669 ms.  0.003: as fast as
+// any, and a render's last call returns in 49 ms.  JADE_CARRY_FRACTION in the environment overrides it (0 = only the
+// absolute floor below).
 #ifndef JADE_CARRY_FRACTION
-#define JADE_CARRY_FRACTION 0.02
+#define JADE_CARRY_FRACTION 0.003
 #endif
 #ifndef JADE_CARRY_RECORDS
 #define JADE_CARRY_RECORDS 32768u /* ... and in any case once fewer than this (and < 0.1 % of its records) are active */

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--closeup", action="store_true")
+    ap.add_argument("--reference-walk", action="store_true", help="jade_render_params.walk = JADE_WALK_REFERENCE (default: early exits, as bench.py)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "trace_stalls.json"))
     a = ap.parse_args()
     os.environ["JADE_HIP_LIB"] = os.path.join(ROOT, "jaderaytracerendering_amd", "lib", "libjade_hip_prof.so")
@@ -43,7 +44,7 @@ def main():
         centre = hs.vertices()[hs.tri_i32()[:, 0] == 0].reshape(-1, 3).mean(0)
         forward = -np.array(cfg.camera[8:11], np.float32)
         eye = [float(x) for x in centre - 0.22 * forward]
-    p = B.make_params(cfg.width, cfg.height, a.spp * (a.steps + 1), eye, list(cfg.camera))
+    p = B.make_params(cfg.width, cfg.height, a.spp * (a.steps + 1), eye, list(cfg.camera), walk=0 if a.reference_walk else 1)
     buf = (ctypes.c_ulonglong * 64)()
     with hip.scene(hs) as sc:
         sc.begin(p)
