@@ -201,6 +201,9 @@ static void hist_add(int which, uint64_t v) {
   __sync_fetch_and_add(&g_visit_hist[which][b], 1);
 }
 
+#ifdef JADE_ORACLE_PROBE
+/* NOT in libjade_oracle.so: only `make -C oracle probe` (libjade_oracle_probe.so, used by tools/prune_probe.py alone) compiles
+ * this in, so the checker the parity tests load holds nothing but the reference's walk. */
 /* Diagnostics only (not part of jade_rt.h, and NOT the reference's algorithm): a walk that leaves out children whose box
  * begins farther along the ray than the nearest hit found so far - what SURVEY section 7 step 5 calls "optional distance
  * pruning".  tools/prune_probe.py uses it to count what such a walk visits and whether the frame keeps its bits; the
@@ -282,9 +285,13 @@ static HitResult hit_bvh_pruned(const jade_scene* s, Ray ray, int src_object_idx
   return res;
 }
 
+#endif /* JADE_ORACLE_PROBE */
+
 /* PathTrace.cu:795-859 */
 static HitResult hit_bvh(const jade_scene* s, Ray ray, int src_object_idx, counters* c) {
-  if (g_prune_mode) return hit_bvh_pruned(s, ray, src_object_idx, c); /* (diagnostics, see above: never set by the tests' checker) */
+#ifdef JADE_ORACLE_PROBE
+  if (g_prune_mode) return hit_bvh_pruned(s, ray, src_object_idx, c); /* (the probe build only, see above) */
+#endif
   HitResult res;
   res.isHit = 0;
   res.index = 0;

@@ -15,7 +15,9 @@ from jaderaytracerendering_amd import _abi, backend as B  # noqa: E402
 name = sys.argv[1] if len(sys.argv) > 1 else "C3"
 W, H, SPP = (int(x) for x in sys.argv[2:5]) if len(sys.argv) > 4 else (480, 270, 8)
 hs, cfg = J.build_config(name)
-be = B.Backend(os.path.join(ROOT, "oracle", "libjade_oracle.so"))
+import subprocess  # noqa: E402
+subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "probe"])
+be = B.Backend(os.path.join(ROOT, "oracle", "libjade_oracle_probe.so"))  # the probe build: libjade_oracle.so has no such walk
 lib = be.lib
 lib.jade_oracle_set_prune.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float]
 lib.jade_oracle_set_prune.restype = None
