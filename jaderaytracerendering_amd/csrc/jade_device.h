@@ -78,8 +78,19 @@ struct DevMaterial {  // 64 bytes; field names as in jade_triangle
   int32_t obj_idx;
 };
 
+// The four-wide form of the walk (round 3, jade_trace.h "Wide walk"): with early exits a visit tests a node's four GRANDCHILDREN.
+// nodes4: 8 x float4 per internal node, same numbering as `nodes`: {half 0: the three box float4 of the left child's record}
+// {half 1: the right child's} {four references} {unused}; a child that is a leaf fills its half with its own box twice and the
+// references (leaf, JADE_REF_NONE).  Null when the tree has a missing child (general_walk).
+#ifndef JADE_WIDE_WALK
+#define JADE_WIDE_WALK 1
+#endif
+#ifndef JADE_TRACE_TOP4
+#define JADE_TRACE_TOP4 72 /* wide records k_trace stages in LDS: 7 planes x 72 x 16 B = 8 064 B */
+#endif
 struct DevScene {
   const float4* nodes;        // 4 x float4 per internal node
+  const float4* nodes4;       // 8 x float4 per internal node (see above), or null
   const float4* tverts;       // 5 x float4 per pair of triangles of a leaf (jade_trace.h)
   const jade_triangle* tris;  // the caller's records (BVH order): read for vertices only (emitters, the BSSRDF exit triangle)
   const float4* tnorm;        // per triangle {flat normal, number of its DevMaterial (uint bits)}

@@ -545,8 +545,11 @@ static __device__ __forceinline__ void nt_st4(float4* p, float x, float y, float
 #ifndef JADE_TRACE_WAVES
 #define JADE_TRACE_WAVES 5 /* waves per SIMD the register allocation leaves room for: 5 = at most 96 VGPRs (12 bytes of scratch) and 5 x 31 KB of LDS per CU.  Round 3, same process, C3 / statue close-up: 4 waves (102 VGPRs) 133.6 / 1037 ms of k_trace per 256-spp step, 5 waves 126.9 / 983 (round 2's "5 and 6 blocks per CU are no faster" was measured on a 102-VGPR build, which the hardware never ran at more than 4) */
 #endif
-__global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(DevScene S, PathState P, const uint32_t* queue, QueueCtl* qc,
-                                                           uint32_t* spill, DevCounters* ctr, uint32_t chunk) {
+// WIDE: the walk may take wide units (jade_trace.h, "Wide walk"): k_trace_wide, launched instead of k_trace for renders with
+// early exits on trees that have wide records.
+template <bool WIDE>
+static __device__ __forceinline__ void trace_body(const DevScene& S, const PathState& P, const uint32_t* queue, QueueCtl* qc, uint32_t* spill, DevCounters* ctr,
+                                                  uint32_t chunk) {
   __shared__ uint32_t lds_cols[TW_END * JADE_TRACE_BLOCK];
   __shared__ __attribute__((aligned(8))) uint32_t lds_wq[JADE_TRACE_BLOCK / 64][2 * JADE_WQ];  // a wave's ring of leaves to test (jade_trace.h)
   __shared__ __attribute__((aligned(8))) uint32_t lds_hq[JADE_TRACE_BLOCK / 64][2 * JADE_HQ];  // and its ring of hit candidates  // a wave's queue of leaves to test (jade_trace.h)
@@ -559,6 +562,8 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
   stk.stride_spill = gridDim.x * blockDim.x;
   stk.top = nullptr;
   stk.top_k = 0;
+  stk.top4 = nullptr;
+  stk.top4_k = 0;
   if (qc->count == 0) return;  // (a pass of a batch behind the one that ended the step: nothing was queued)
   // The grid is sized for a full queue (in a batch of passes the host does not know the length); a short queue keeps one
   // block per JADE_TRACE_BLOCK rays and the others leave before they stage anything: the thin passes at the end of a render
@@ -566,8 +571,20 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
   // chunks until the queue is empty, as ever.
   if ((unsigned long long)blockIdx.x * JADE_TRACE_BLOCK >= (unsigned long long)qc->count) return;
 #if JADE_TRACE_TOP_NODES > 0 && JADE_LDS_TOP_NODES > 0
+  static_assert(7 * JADE_TRACE_TOP4 <= 4 * JADE_TRACE_TOP_NODES, "the wide top shares the binary top's LDS");
   __shared__ float4 lds_top[4 * JADE_TRACE_TOP_NODES];
-  {  // stage the top of the tree: record i's j-th 16 bytes -> plane j, entry i (coalesced reads of S.nodes)
+  if (WIDE) {
+    // the top of the tree as wide records, seven planes (the eighth 16 bytes of a record are unused); a binary unit in this
+    // kernel (a ray walked again after a tie, a ray with a non-finite 1/d) reads its records from memory
+    const uint32_t k = S.top_k < JADE_TRACE_TOP4 ? S.top_k : JADE_TRACE_TOP4;
+    for (uint32_t i = threadIdx.x; i < 8u * k; i += JADE_TRACE_BLOCK)
+      if ((i & 7u) != 7u) lds_top[(i & 7u) * JADE_TRACE_TOP4 + (i >> 3)] = S.nodes4[i];
+    __syncthreads();
+    stk.top4 = lds_top;
+    stk.top4_k = k;
+    stk.top = lds_top;  // (node_fetch reads entry 0 of four planes for every lane and ignores it: top_k = 0)
+    stk.top_k = 0;
+  } else {  // stage the top of the tree: record i's j-th 16 bytes -> plane j, entry i (coalesced reads of S.nodes)
     const uint32_t k = S.top_k < JADE_TRACE_TOP_NODES ? S.top_k : JADE_TRACE_TOP_NODES;
     for (uint32_t i = threadIdx.x; i < 4u * k; i += JADE_TRACE_BLOCK) lds_top[(i & 3u) * JADE_TRACE_TOP_NODES + (i >> 2)] = S.nodes[i];
     __syncthreads();
@@ -602,7 +619,7 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
   r.pre.rf = make_uint2(0u, 0u);
 #endif
   WaveTrace wt;  // the wave's rings of leaves to test and of hit candidates, and the item this lane is testing (jade_trace.h)
-  wt.init(lds_addr_of(&lds_wq[threadIdx.x >> 6][0]), lds_addr_of(&lds_hq[threadIdx.x >> 6][0]), lane);
+  wt.init(lds_addr_of(&lds_wq[threadIdx.x >> 6][0]), lds_addr_of(&lds_hq[threadIdx.x >> 6][0]), lane, WIDE);
 #if JADE_COOP_LEAF
   __shared__ __attribute__((aligned(16))) uint32_t lds_stage[JADE_TRACE_BLOCK / 64][64 * 20];
   wt.stage = lds_addr_of(&lds_stage[threadIdx.x >> 6][0]);
@@ -615,8 +632,21 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
   for (;;) {
     // ---- a ray has ended when its walk has and all the leaves it pushed have been finished
     if (active && WaveTrace::ray_ended(r, stk)) {
-      active = false;
-      wb = true;
+      // (wide walk: two leaves tied for this ray's best distance and the walk was not the reference's order - once more, with
+      // binary units only; a ray that ended early has its answer whatever the order)
+      const bool again = WIDE && lds_get(stk, TW_LIMIT) == JADE_LIMIT_TIE && (r.skipx & (JADE_CUT | JADE_FORCE_BINARY)) == 0u;
+      if (again) {
+        const uint32_t p = my_e / (uint32_t)P.nslots;
+        const float4 og = nt_ld4(&P.orgs[p]);
+        const int32_t skip = __float_as_int(og.w);
+        const jvec3 o = skip == JADE_SKIP_CAMERA ? jv(P.eye[0], P.eye[1], P.eye[2]) : jv(og.x, og.y, og.z);
+        const float4 dv = nt_ld4(&P.slot[(size_t)my_e * 2]);
+        walk_begin(r, stk, S, o, jv(dv.x, dv.y, dv.z), skip, P.early_exit ? dv.w : __int_as_float(-1));
+        r.skipx |= JADE_FORCE_BINARY;
+      } else {
+        active = false;
+        wb = true;
+      }
     }
     // ---- once enough lanes are idle (or all are): write their results back and refill them.  Both are done for >=
     // JADE_REFILL_MIN lanes at a time, not whenever a single ray ends: a block of code that
@@ -675,7 +705,7 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
     }
     if (n_idle == 64 && queue_empty) break;  // nothing in flight (so no leaf is waiting either), nothing left to claim
     // ---- one iteration of work for the wave: walk units, test units or a pass over the hit candidates (jade_trace.h)
-    wt.iterate(r, active, S, stk, vcnt, tcnt, pr);
+    wt.template iterate<WIDE>(r, active, S, stk, vcnt, tcnt, pr);
   }
 #if JADE_TRACE_PROFILE
   pr.count(PC_WAVES, 1);
@@ -693,6 +723,17 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
     if (T) atomicAdd(&cs->tris_tested, (unsigned long long)T);
   }
 }
+__global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(DevScene S, PathState P, const uint32_t* queue, QueueCtl* qc,
+                                                           uint32_t* spill, DevCounters* ctr, uint32_t chunk) {
+  trace_body<false>(S, P, queue, qc, spill, ctr, chunk);
+}
+__global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace_wide(DevScene S, PathState P, const uint32_t* queue, QueueCtl* qc,
+                                                                uint32_t* spill, DevCounters* ctr, uint32_t chunk) {
+  trace_body<true>(S, P, queue, qc, spill, ctr, chunk);
+}
+// which of the two a launch takes: wide units need early exits (the order of the walk is then nobody's business but a tie's) and
+// a tree with wide records
+static inline bool trace_wide(const DevScene& S, const PathState& P) { return JADE_WIDE_WALK && P.early_exit && S.nodes4 != nullptr; }
 
 // ---------------------------------------------------------------------------------------------------------------
 // k_light: the first pass of a step, fused.  Most samples of most frames are LIGHT: the camera ray misses (sky), or it
@@ -1394,6 +1435,8 @@ struct Tunables {
   uint32_t sort_min = 65536;  // JADE_SORT_MIN: queues shorter than this are traced as they are
   bool light_packet = true;   // JADE_LIGHT_PACKET=0: the fused first pass walks its rays per lane (k_light) instead of as packets
   int packet_budget = JADE_PACKET_BUDGET;  // JADE_PACKET_BUDGET: records a packet may read before it is given up and walked per lane
+  int wide_mode = -1;         // JADE_WIDE: with early exits k_trace walks four grandchildren per visit (k_trace_wide): 1 always, 0 never, unset =
+                              // when the traversal's records do not fit the L2 (the rule of sort_mode; jade_scene_create then builds wide records)
   void read() {
     auto flag0 = [](const char* n) { const char* e = getenv(n); return e && atoi(e) == 0; };
     auto flag1 = [](const char* n) { const char* e = getenv(n); return e && atoi(e) > 0; };
@@ -1411,6 +1454,7 @@ struct Tunables {
     if (const char* e = getenv("JADE_SORT")) sort_mode = atoi(e) > 0 ? 1 : 0;
     if (const char* e = getenv("JADE_SORT_MIN")) sort_min = (uint32_t)atoi(e);
     if (const char* e = getenv("JADE_PACKET_BUDGET")) packet_budget = atoi(e);
+    if (const char* e = getenv("JADE_WIDE")) wide_mode = atoi(e) > 0 ? 1 : 0;
   }
 };
 
@@ -1419,7 +1463,7 @@ struct jade_scene {
   Tunables tun;
   hipStream_t stream = nullptr;
   DevScene dev{};
-  DevBuf b_nodes, b_tverts, b_tris, b_emit, b_mapping, b_prefix, b_segs, b_env, b_guide, b_guide_obj, b_tnorm, b_mats;
+  DevBuf b_nodes, b_nodes4, b_tverts, b_tris, b_emit, b_mapping, b_prefix, b_segs, b_env, b_guide, b_guide_obj, b_tnorm, b_mats;
   int n_emit = 0;
   int bvh_depth = 0;
   bool sort_rays = false;     // the ray queue is ordered before every k_trace launch (Tunables.sort_mode; then passes are host-followed)
@@ -1716,6 +1760,45 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
     uint32_t refs[4] = {ref_of(nd.left), ref_of(nd.right), 0u, 0u};
     memcpy(&o[3], refs, 16);
   }
+  // the four-wide records (jade_device.h): node i's record holds its grandchildren - each child's own record, or the child twice
+  // if it is a leaf
+  // Built where the wide walk pays: measured with early exits, same process, k_trace per step: C5 (55 MB of node + pair records, bound
+  // by dependent 64-B sector misses) 180.0 -> 166.6 ms; C3 (3.8 MB, L2-resident: a unit's own instructions count, and a wide unit
+  // has more of them) 106.7 -> 110.2 ms, close-up 723 -> 755.  So: the rule of the ordered ray queue (JADE_SORT_GEOMETRY_BYTES);
+  // JADE_WIDE=0 / 1 overrides it.
+  std::vector<float4> nodes4;
+  Tunables tun0;
+  tun0.read();
+  const size_t geometry_bytes0 = ((size_t)4 * std::max(n_internal, 1) + (size_t)5 * std::max<size_t>(n_pairs, 1)) * sizeof(float4);
+  const bool want_wide = tun0.wide_mode < 0 ? geometry_bytes0 > JADE_SORT_GEOMETRY_BYTES : tun0.wide_mode > 0;
+  if (JADE_WIDE_WALK && want_wide && !missing_child && n_internal > 0) {
+    nodes4.assign((size_t)8 * n_internal, make_float4(0, 0, 0, 0));
+    for (int i = 1; i < nN; ++i) {
+      const jade_bvh_node& nd = d->nodes[i];
+      if (nd.n > 0 || compact[i] < 0) continue;
+      float4* o = &nodes4[(size_t)8 * compact[i]];
+      uint32_t refs[4];
+      const int ch[2] = {nd.left, nd.right};
+      for (int h = 0; h < 2; ++h) {
+        const jade_bvh_node& c = d->nodes[ch[h]];
+        if (c.n > 0) {  // a leaf: its own box in both lanes of the half, one reference
+          o[3 * h + 0] = make_float4(c.aa[0], c.aa[0], c.aa[1], c.aa[1]);
+          o[3 * h + 1] = make_float4(c.aa[2], c.aa[2], c.bb[0], c.bb[0]);
+          o[3 * h + 2] = make_float4(c.bb[1], c.bb[1], c.bb[2], c.bb[2]);
+          refs[2 * h] = ref_of(ch[h]);
+          refs[2 * h + 1] = JADE_REF_NONE;
+        } else {
+          const float4* src = &nodes[(size_t)4 * compact[ch[h]]];
+          o[3 * h + 0] = src[0];
+          o[3 * h + 1] = src[1];
+          o[3 * h + 2] = src[2];
+          refs[2 * h] = ref_of(c.left);
+          refs[2 * h + 1] = ref_of(c.right);
+        }
+      }
+      memcpy(&o[6], refs, 16);
+    }
+  }
   std::vector<float4> tverts((size_t)5 * std::max<size_t>(n_pairs, 1));
   for (int i = 1; i < nN; ++i) {
     const jade_bvh_node& nd = d->nodes[i];
@@ -1819,6 +1902,7 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
   s->bvh_depth = depth;
   hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = upload(s->b_nodes, nodes.data(), nodes.size(), s->stream);
+  if (e == hipSuccess && !nodes4.empty()) e = upload(s->b_nodes4, nodes4.data(), nodes4.size(), s->stream);
   if (e == hipSuccess) e = upload(s->b_tverts, tverts.data(), tverts.size(), s->stream);
   if (e == hipSuccess) e = upload(s->b_tris, d->triangles, (size_t)d->n_triangles, s->stream);
   if (e == hipSuccess) e = upload(s->b_emit, d->emit_indices, (size_t)d->n_emit, s->stream);
@@ -1837,6 +1921,7 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
     return fail(e == hipErrorOutOfMemory ? JADE_ERR_NOMEM : JADE_ERR_DEVICE, std::string("scene upload: ") + hipGetErrorString(e));
   }
   s->dev.nodes = s->b_nodes.as<float4>();
+  s->dev.nodes4 = nodes4.empty() ? nullptr : s->b_nodes4.as<float4>();
   s->dev.tverts = s->b_tverts.as<float4>();
   s->dev.tris = s->b_tris.as<jade_triangle>();
   s->dev.emit = s->b_emit.as<int32_t>();
@@ -2141,7 +2226,7 @@ static int run_passes(jade_scene* s, int64_t from_spp, uint32_t target_spp, bool
                            j ? qc + (j - 1) : (const QueueCtl*)nullptr, stop_below);
         cur ^= 1;
         HIP_TRY(hipEventRecord(s->ev_batch[2 * j], s->stream));
-        hipLaunchKernelGGL(k_trace, dim3((unsigned)s->trace_blocks), dim3(JADE_TRACE_BLOCK), 0, s->stream, s->dev, s->ps,
+        hipLaunchKernelGGL(trace_wide(s->dev, s->ps) ? k_trace_wide : k_trace, dim3((unsigned)s->trace_blocks), dim3(JADE_TRACE_BLOCK), 0, s->stream, s->dev, s->ps,
                            s->b_queue.as<uint32_t>(), qc + j, s->b_spill.as<uint32_t>(), s->b_ctr.as<DevCounters>(), 0u);
         HIP_TRY(hipEventRecord(s->ev_batch[2 * j + 1], s->stream));
       }
@@ -2305,7 +2390,7 @@ static int run_passes(jade_scene* s, int64_t from_spp, uint32_t target_spp, bool
                                         s->b_sortq.as<uint32_t>(), (size_t)n, 0u, 32u, s->stream));
       trace_queue = s->b_sortq.as<uint32_t>();
     }
-    hipLaunchKernelGGL(k_trace, dim3((unsigned)s->trace_blocks), dim3(JADE_TRACE_BLOCK), 0, s->stream, s->dev, s->ps,
+    hipLaunchKernelGGL(trace_wide(s->dev, s->ps) ? k_trace_wide : k_trace, dim3((unsigned)s->trace_blocks), dim3(JADE_TRACE_BLOCK), 0, s->stream, s->dev, s->ps,
                        trace_queue, qc, s->b_spill.as<uint32_t>(), s->b_ctr.as<DevCounters>(),
                        trace_chunk(s, host_ctl[0]));
     HIP_TRY(hipGetLastError());
@@ -2707,7 +2792,7 @@ static int trace_rays_impl(jade_scene* s, int32_t n, const float* origins, const
   HIP_TRY(ev0.create());
   HIP_TRY(ev1.create());
   HIP_TRY(hipEventRecord(ev0.e, s->stream));
-  hipLaunchKernelGGL(k_trace, dim3((unsigned)s->trace_blocks), dim3(JADE_TRACE_BLOCK), 0, s->stream, s->dev, P, b_q.as<uint32_t>(),
+  hipLaunchKernelGGL(trace_wide(s->dev, P) ? k_trace_wide : k_trace, dim3((unsigned)s->trace_blocks), dim3(JADE_TRACE_BLOCK), 0, s->stream, s->dev, P, b_q.as<uint32_t>(),
                      s->b_ctl.as<QueueCtl>(), b_spill.as<uint32_t>(), s->b_ctr.as<DevCounters>(), trace_chunk(s, (uint32_t)n));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(ev1.e, s->stream));

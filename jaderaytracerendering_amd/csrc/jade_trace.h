@@ -135,6 +135,8 @@ struct LdsStack {
   uint32_t stride_spill;
   const float4* top;   // LDS copy of node records [0, top_k): four planes of float4 (plane j = the record's j-th 16 bytes)
   uint32_t top_k;
+  const float4* top4;  // wide walk: LDS copy of the wide records [0, top4_k), seven planes of JADE_TRACE_TOP4 float4
+  uint32_t top4_k;
 };
 enum {
   LW_FIFO = JADE_LDS_STACK,  // JADE_LDS_FIFO leaf cursors waiting for their triangle tests (ring)
@@ -434,6 +436,106 @@ static __device__ __forceinline__ uint32_t node_core(uint32_t& cur_io, uint32_t&
   return node_decide<GENERAL, W_INV, W_DUMMY>(nr, cur_io, sp_io, od, stk, room, vcnt, inv_reg);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Wide walk (round 3; k_trace with early exits only).  hitAABB is monotone in float32: a child's box lies inside its parent's
+// exactly, every step of the slab test is a monotone function of the box's coordinates, and the return rule keeps "> 0" under
+// enlargement (tools/box_monotone_probe.py) - a ray that meets a node's box meets every ancestor's, with the values as computed.
+// So the leaves hitBVH tests for a ray are {leaves whose own box it meets}; the inner nodes decide only the ORDER in which they
+// are met, which matters to nobody but hitArray's tie rule (:787).  A wide unit visits a node by testing its four GRANDCHILDREN
+// (jade_device.h, nodes4) and never looks at the two children: half the dependent record fetches.  Same reference space, same
+// stack, same leaf ring as the binary unit - a ray can take either kind of unit at any node.  The order of a wide walk is not
+// the reference's, so whenever two candidates from different leaves tie for a ray's best distance the ray is walked again with
+// binary units only (JADE_LIMIT_TIE, JADE_FORCE_BINARY: k_trace); rays with a non-finite 1/d take the binary general unit as ever.
+// A leaf chosen as the next node is queued by the following unit (as a leaf that comes off the stack is).
+// ---------------------------------------------------------------------------------------------------------------
+struct NodeRec4 {
+  float4 a0, b0, c0, a1, b1, c1;
+  uint4 rf;
+};
+static __device__ __forceinline__ NodeRec4 node_fetch4(uint32_t cur, const DevScene& S, const LdsStack& stk) {
+  const bool is_leaf = (int32_t)cur < 0;
+  const uint32_t node = is_leaf ? 0u : cur;
+  const bool in_top = node < stk.top4_k;
+  const float4* t = stk.top4 + (in_top ? node : 0u);
+  NodeRec4 n;
+  n.a0 = t[0];
+  n.b0 = t[JADE_TRACE_TOP4];
+  n.c0 = t[2 * JADE_TRACE_TOP4];
+  n.a1 = t[3 * JADE_TRACE_TOP4];
+  n.b1 = t[4 * JADE_TRACE_TOP4];
+  n.c1 = t[5 * JADE_TRACE_TOP4];
+  const float4 lr = t[6 * JADE_TRACE_TOP4];
+  n.rf = make_uint4(jade_f2u(lr.x), jade_f2u(lr.y), jade_f2u(lr.z), jade_f2u(lr.w));
+  // (opaque: "LDS or global" would become FLAT loads through a selected generic pointer, see node_fetch)
+  asm volatile("" : "+v"(n.a0.x), "+v"(n.a0.y), "+v"(n.a0.z), "+v"(n.a0.w), "+v"(n.b0.x), "+v"(n.b0.y), "+v"(n.b0.z), "+v"(n.b0.w));
+  asm volatile("" : "+v"(n.c0.x), "+v"(n.c0.y), "+v"(n.c0.z), "+v"(n.c0.w), "+v"(n.a1.x), "+v"(n.a1.y), "+v"(n.a1.z), "+v"(n.a1.w));
+  asm volatile("" : "+v"(n.b1.x), "+v"(n.b1.y), "+v"(n.b1.z), "+v"(n.b1.w), "+v"(n.c1.x), "+v"(n.c1.y), "+v"(n.c1.z), "+v"(n.c1.w));
+  asm volatile("" : "+v"(n.rf.x), "+v"(n.rf.y), "+v"(n.rf.z), "+v"(n.rf.w));
+  if (!in_top) {
+    const float4* nd = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.nodes4) + (size_t)node * 128u);
+    n.a0 = nd[0];
+    n.b0 = nd[1];
+    n.c0 = nd[2];
+    n.a1 = nd[3];
+    n.b1 = nd[4];
+    n.c1 = nd[5];
+    n.rf = *reinterpret_cast<const uint4*>(nd + 6);
+  }
+  return n;
+}
+template <int W_DUMMY>
+static __device__ __forceinline__ uint32_t node_decide4(const NodeRec4& nr, uint32_t& cur_io, uint32_t& sp_io, const RayOD& od, const LdsStack& stk,
+                                                        uint32_t& vcnt, const jvec3& inv) {
+  const uint32_t cur = cur_io;
+  const bool is_leaf = (int32_t)cur < 0;
+  float d0, d1, d2, d3;
+  slab2(od, inv, nr.a0, nr.b0, nr.c0, false, &d0, &d1);
+  slab2(od, inv, nr.a1, nr.b1, nr.c1, false, &d2, &d3);
+  const uint4 rf = nr.rf;
+  const bool v1 = rf.y != JADE_REF_NONE, v3 = rf.w != JADE_REF_NONE;  // (slots 0 and 2 always hold a child)
+  vcnt += is_leaf ? 0u : 2u + (v1 ? 1u : 0u) + (v3 ? 1u : 0u);
+  const bool in0 = !is_leaf && d0 > 0, in1 = !is_leaf && v1 && d1 > 0, in2 = !is_leaf && d2 > 0, in3 = !is_leaf && v3 && d3 > 0;
+  // the nearest of the boxes met is next; of the others, the pair it does not belong to goes onto the stack first (it comes off
+  // last), its sibling last
+  const bool s01 = in1 && (!in0 || d1 < d0), s23 = in3 && (!in2 || d3 < d2);  // the nearer of each pair is its second member
+  const float m01 = s01 ? d1 : d0, m23 = s23 ? d3 : d2;
+  const bool nin01 = in0 || in1, nin23 = in2 || in3;                           // a pair has a box that is met
+  const bool p1 = nin23 && (!nin01 || m23 < m01);                              // the nearest of all lies in pair 1
+  const bool any = nin01 || nin23;
+  const uint32_t n01 = s01 ? rf.y : rf.x, f01 = s01 ? rf.x : rf.y, n23 = s23 ? rf.w : rf.z, f23 = s23 ? rf.z : rf.w;
+  const bool fin01 = s01 ? in0 : in1, fin23 = s23 ? in2 : in3;  // the farther one of each pair is met too
+  const uint32_t next = p1 ? n23 : n01;
+  // pushes, in this order: other pair's farther, other pair's nearer, own pair's farther
+  const uint32_t q0 = p1 ? f01 : f23, q1 = p1 ? n01 : n23, q2 = p1 ? f23 : f01;
+  const bool w0 = p1 ? fin01 : fin23, w1 = p1 ? nin01 : nin23, w2 = p1 ? fin23 : fin01;
+  const uint32_t dummy = stk.col + W_DUMMY * JADE_COL_STRIDE;
+  const uint32_t lds_end = stk.col + JADE_LDS_STACK * JADE_COL_STRIDE;
+  uint32_t sp = sp_io;
+  lds_st((w0 && sp < lds_end) ? sp : dummy, q0);
+  if (w0 && sp >= lds_end) stk.spill[(size_t)((sp - lds_end) / JADE_COL_STRIDE) * stk.stride_spill] = q0;  // rare
+  sp += w0 ? JADE_COL_STRIDE : 0u;
+  lds_st((w1 && sp < lds_end) ? sp : dummy, q1);
+  if (w1 && sp >= lds_end) stk.spill[(size_t)((sp - lds_end) / JADE_COL_STRIDE) * stk.stride_spill] = q1;
+  sp += w1 ? JADE_COL_STRIDE : 0u;
+  lds_st((w2 && sp < lds_end) ? sp : dummy, q2);
+  if (w2 && sp >= lds_end) stk.spill[(size_t)((sp - lds_end) / JADE_COL_STRIDE) * stk.stride_spill] = q2;
+  sp += w2 ? JADE_COL_STRIDE : 0u;
+  // ---- the nearest box is a leaf's: it is queued by this very unit and the walk goes on with what comes off the stack - which
+  // may be what this unit has just pushed: a write and a read of the same LDS word in program order; a stack that has outgrown
+  // its LDS levels leaves the leaf to the next unit instead
+  const bool leaf_now = !is_leaf && any && (int32_t)next < 0 && sp_io + 3u * JADE_COL_STRIDE <= lds_end;
+  // ---- pop: a leaf that was queued by this unit, or a node none of whose boxes is met (such a lane pushed nothing)
+  const bool need_pop = is_leaf || !any || leaf_now;
+  const bool do_pop = need_pop && sp != stk.col;
+  const uint32_t sp1 = sp - JADE_COL_STRIDE;
+  uint32_t top = lds_ld((do_pop && sp1 < lds_end) ? sp1 : dummy);
+  asm volatile("" : "+v"(top));
+  if (do_pop && sp1 >= lds_end) top = stk.spill[(size_t)((sp1 - lds_end) / JADE_COL_STRIDE) * stk.stride_spill];  // rare (never after leaf_now)
+  sp_io = do_pop ? sp1 : sp;
+  cur_io = need_pop ? (do_pop ? top : JADE_REF_NONE) : next;
+  return is_leaf ? cur : (leaf_now ? next : 0u);
+}
+
 // The walk with a FIFO of leaf cursors per lane (k_light): one unit for a lane with ray_can_walk.
 template <bool GENERAL>
 static __device__ __forceinline__ void ray_step_node_s(RayState& r, const DevScene& S, const LdsStack& stk, uint32_t& vcnt) {
@@ -603,6 +705,7 @@ static __device__ __forceinline__ void ray_step_tri_s(RayState& r, const DevScen
 // in registers: the kernel runs 4 waves per SIMD and has them to spare).
 // ---------------------------------------------------------------------------------------------------------------
 enum { TW_BEST_DIST = JADE_LDS_STACK, TW_BEST_SEQ, TW_BEST_REF, TW_FINISHED, TW_DUMMY, TW_LIMIT, TW_END };
+#define JADE_LIMIT_TIE 0x7fc00001u /* TW_LIMIT of a ray of the wide walk for whose best distance two leaves tied: a NaN (no early exit any more); k_trace walks the ray again with binary units */
 #ifndef JADE_WQ
 #define JADE_WQ 128 /* items a wave's ring holds (a power of two, >= 128: a walk unit may push 64) */
 #endif
@@ -618,8 +721,9 @@ static_assert((JADE_HQ & (JADE_HQ - 1)) == 0 && JADE_HQ >= 128, "JADE_HQ");
 #ifndef JADE_PREFETCH
 #define JADE_PREFETCH 0 /* 1: a walk unit ends by requesting the record of the node the walk goes to next (WalkState.pre), so that its latency passes while the wave pushes leaves, picks its next kind of work, tests triangles */
 #endif
-#define JADE_CUT 0x40000000u       /* WalkState.skipx: the ray has its answer (early exit) */
-#define JADE_SKIP_MASK 0x3fffffffu /* ... its source triangle (all ones = none; triangle indices stay below 2^27) */
+#define JADE_CUT 0x40000000u          /* WalkState.skipx: the ray has its answer (early exit) */
+#define JADE_FORCE_BINARY 0x20000000u /* ... this ray takes binary units only (it is being walked again after a tie, "Wide walk") */
+#define JADE_SKIP_MASK 0x1fffffffu    /* ... its source triangle (all ones = none; triangle indices stay below 2^27) */
 struct WalkState {
 #if JADE_PREFETCH
   NodeRec pre;      // the record of `cur`, requested when cur was set
@@ -669,6 +773,13 @@ static __device__ __forceinline__ uint32_t walk_step(WalkState& r, const DevScen
   return (leafv & 15u) != 0 ? leafv : 0u;  // (an empty leaf cannot happen for a valid BVH)
 }
 
+// One WIDE unit of the walk ("Wide walk" above) for a lane whose walk has not ended.
+static __device__ __forceinline__ uint32_t walk_step4(WalkState& r, const DevScene& S, const LdsStack& stk, uint32_t& vcnt) {
+  const NodeRec4 nr = node_fetch4(r.cur, S, stk);
+  const uint32_t leafv = node_decide4<TW_DUMMY>(nr, r.cur, r.sp, r.od, stk, vcnt, r.inv);
+  return (leafv & 15u) != 0 ? leafv : 0u;
+}
+
 // One pair record of the item a lane holds: item_leaf = the leaf cursor (0 afterwards if the leaf is finished), meta =
 // owner lane | sequence << 6, od / skip = the owner's ray (the caller's ds_bpermute), rec = the record (the caller's
 // pair_load, issued before the ds_bpermutes so that the two latencies overlap), lane = this lane.  in_a / in_b: the origin
@@ -697,7 +808,7 @@ static __device__ __forceinline__ void test_step(uint32_t& item_leaf, uint32_t m
 // met as its (meta >> 6)-th.  The barycentric solve and the distance (:732-747), then hitArray's rule for the best hit
 // (:787, strict "<" in the order leaves are met and triangles are indexed), which in terms of the candidates is: smaller
 // distance, then earlier leaf, then earlier triangle of the leaf (ref grows with the index inside a leaf).
-static __device__ __forceinline__ void resolve_hit(uint32_t ref, uint32_t meta, const RayOD& od, const DevScene& S, const LdsStack& stk, int lane) {
+static __device__ __forceinline__ void resolve_hit(uint32_t ref, uint32_t meta, const RayOD& od, const DevScene& S, const LdsStack& stk, int lane, bool wide_kernel) {
   const float4* t0 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.tverts) + (ref & 0x7ffffff0u));
   const uint32_t ocol = stk.col + ((meta & 63u) - (uint32_t)lane) * 4u;  // the owner's column
   const uint32_t seq = meta >> 6;
@@ -713,6 +824,8 @@ static __device__ __forceinline__ void resolve_hit(uint32_t ref, uint32_t meta, 
       const float bd = jade_u2f(lds_ld_v(ocol + TW_BEST_DIST * JADE_COL_STRIDE));
       const uint32_t bs = lds_ld_v(ocol + TW_BEST_SEQ * JADE_COL_STRIDE);
       const uint32_t br = lds_ld_v(ocol + TW_BEST_REF * JADE_COL_STRIDE);
+      // (wide walk: two leaves tie for the best distance - which of them the reference met first is not known: JADE_LIMIT_TIE)
+      if (wide_kernel && dist == bd && seq != bs) lds_st_v(ocol + TW_LIMIT * JADE_COL_STRIDE, JADE_LIMIT_TIE);
       if (!(dist < bd || (dist == bd && (seq < bs || (seq == bs && ref < br))))) {
         waiting = false;
       } else {
@@ -768,8 +881,10 @@ struct WaveTrace {
   uint32_t item_leaf, item_meta; // the leaf this lane is testing (cursor, 0 = none) and its owner | sequence << 6
   uint32_t below_lo, below_hi;   // the lanes below this one, as two 32-bit masks
   int lane;
+  bool wide_kernel;              // the kernel may walk with wide units: ties are marked (resolve_hit)
 
-  __device__ __forceinline__ void init(uint32_t wq_addr, uint32_t hq_addr, int lane_) {
+  __device__ __forceinline__ void init(uint32_t wq_addr, uint32_t hq_addr, int lane_, bool wide_kernel_ = false) {
+    wide_kernel = wide_kernel_;
     wq = wq_addr;
     hq = hq_addr;
     q_head = q_count = h_head = h_count = 0;
@@ -802,7 +917,7 @@ struct WaveTrace {
     h_head = (h_head + nres) & (JADE_HQ - 1u);
     h_count -= nres;
     const RayOD od = ray_of(r, (int)(meta & 63u));
-    if (mine) resolve_hit(ref, meta, od, S, stk, lane);
+    if (mine) resolve_hit(ref, meta, od, S, stk, lane, wide_kernel);
     // Early exit (JADE_WALK_EARLY_EXIT): a ray whose best hit is now nearer than its limit has its answer - its walk ends
     // here (stack dropped) and the leaves it has pushed but that no lane has taken yet are dropped unread (JADE_CUT in
     // skipx, seen by whoever takes one).  A lane without a ray has cur == NONE and sp at its base already.
@@ -820,6 +935,8 @@ struct WaveTrace {
   // holds a ray), or triangle tests, for as many lanes as there are leaves waiting.  The kind that advances more lanes per
   // instruction issued runs; the walk needs room for the 64 leaves one unit of it can push.  When every ray in flight only
   // waits for candidates (fewer than a batch), they are resolved.
+  // WIDE: the kernel walks with wide units ("Wide walk") wherever every walking lane of the wave may.
+  template <bool WIDE>
   __device__ __forceinline__ void iterate(WalkState& r, bool active, const DevScene& S, const LdsStack& stk, uint32_t& vcnt, uint32_t& tcnt, TraceProf& pr) {
     const int nw = __popcll(__ballot(active && r.cur != JADE_REF_NONE));
     const uint32_t n_items = q_count + (uint32_t)__popcll(__ballot(item_leaf != 0));
@@ -837,6 +954,8 @@ struct WaveTrace {
     }
     if (q_count <= JADE_WQ - 64 && nw > 0 && JADE_COST_TRI * (uint32_t)nw >= JADE_COST_NODE * nt) {
       const bool general = S.general_walk || __ballot(active && (int32_t)r.skipx < 0) != 0ull;  // per WAVE (node_core)
+      const bool wide = WIDE && !general && __ballot(active && (r.skipx & JADE_FORCE_BINARY) != 0u) == 0ull;
+      (void)wide;  // (the profile build keeps to binary units)
 #pragma nounroll
       for (int rep = 0; rep < JADE_STEPS_PER_PICK; ++rep) {
         if (q_count > JADE_WQ - 64) break;
@@ -860,7 +979,9 @@ struct WaveTrace {
           PROF_LAP(pr, PL_WALK_MATH);
         }
 #else
-        if (general) {
+        if (WIDE && wide) {
+          if (go) leafv = walk_step4(r, S, stk, vcnt);
+        } else if (general) {
           if (go) leafv = walk_step<true>(r, S, stk, vcnt);
         } else {
           if (go) leafv = walk_step<false>(r, S, stk, vcnt);

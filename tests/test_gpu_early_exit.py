@@ -85,9 +85,12 @@ def test_shadow_limit_is_the_walks_own_distance(oracle, hip, name):
     assert not (seen & (t_o < lim)).any()
 
 
+@pytest.mark.parametrize("wide", ["0", "1"])
 @pytest.mark.parametrize("name", ["tinyjade", "C2"])
-def test_walk_with_a_limit_per_ray(oracle, hip, name):
-    """k_trace on raw rays, each with a limit: NaN (never: the reference's walk), INF (any recorded hit), a distance."""
+def test_walk_with_a_limit_per_ray(oracle, hip, name, wide, monkeypatch):
+    """k_trace on raw rays, each with a limit: NaN (never: the reference's walk), INF (any recorded hit), a distance - with
+    binary units and with wide ones (JADE_WIDE: four grandchildren per visit; by default only for trees outside the L2)."""
+    monkeypatch.setenv("JADE_WIDE", wide)
     hs, _ = config_scene(name)
     n = 40000
     o, d, skip, _ = _aimed_rays(hs, n, 9)
@@ -119,9 +122,11 @@ def _closeup(hs, cfg):
     return [float(x) for x in centre - 0.22 * (-np.array(cfg.camera[8:11], np.float32))]
 
 
-def test_statue_closeup_frames_are_the_same_bits(oracle, hip):
+@pytest.mark.parametrize("wide", ["0", "1"])
+def test_statue_closeup_frames_are_the_same_bits(oracle, hip, wide, monkeypatch):
     """The frame that is all jade paths (bench.py's statue_closeup view): both walks on the GPU bit for bit, the oracle beside
     them - and the early exits do leave out a good part of the work there."""
+    monkeypatch.setenv("JADE_WIDE", wide)
     hs, cfg = config_scene("C3")
     eye = _closeup(hs, cfg)
     p = B.make_params(96, 64, 24, eye, list(cfg.camera))
@@ -163,3 +168,66 @@ def test_unknown_walk_is_refused(hip):
     with hip.scene(hs) as sc:
         with pytest.raises(B.JadeError):
             sc.render(p)
+
+
+def _twin_scene(twin_light=False):
+    """Every triangle of the ball exists twice at the same place (and, with twin_light, the light too): nearly every hit has a
+    twin at exactly the same distance, most of them in another leaf."""
+    from jaderaytracerendering_amd import host as H
+    b = J.SceneBuilder()
+    cfg = b.config("tinyjade" if twin_light else "tiny")
+    mat = H.material(brdf=(0.5,) * 3)
+    for _ in range(2):
+        b.add_proc("geodesic", 3, mat, H.transform_matrix(trans=(0.1, -1.2, 1.0), scale=(1.1, 1.1, 1.1)))
+    if twin_light:
+        light = H.material(emissive=(30.0,) * 3, brdf=(0.3,) * 3)
+        for _ in range(2):
+            b.add_proc("geodesic", 0, light, H.transform_matrix(trans=(0.4, 1.0, 1.3), scale=(0.3, 0.3, 0.3)))
+    b.set_env_sky(16, 8)
+    return b.build(), cfg
+
+
+def test_wide_walk_ties_are_walked_again_in_the_references_order(oracle, hip, monkeypatch):
+    """With early exits k_trace walks four grandchildren per visit (jade_trace.h, "Wide walk") - an order of leaves that is not
+    the reference's, which only hitArray's tie rule can see (strict "<": of two equal distances the one met first wins,
+    PathTrace.cu:787).  A ray for whose best distance two leaves tie is walked again with binary units; on twin geometry that is
+    nearly every ray, and index, distance and hit point must be the oracle's for every one of them."""
+    monkeypatch.setenv("JADE_WIDE", "1")  # (by default only trees that do not fit the L2 get wide records)
+    hs, _ = _twin_scene()
+    rng = np.random.default_rng(77)
+    flat = hs.vertices().reshape(-1, 3)
+    lo, hi = flat.min(0), flat.max(0)
+    n = 60000
+    o = ((lo + hi) / 2 + (rng.random((n, 3)) - 0.5) * (hi - lo).max() * 1.5).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    skip = np.full(n, -1, np.int32)
+    never = np.full(n, np.float32(np.nan))
+    never.view(np.int32)[:] = -1  # the nearest hit is wanted: the reference's answer, whatever the form of the walk
+    with oracle.scene(hs) as so, hip.scene(hs) as sh:
+        i_o, t_o, p_o, _ = so.trace_rays(o, d, skip)
+        i_w, t_w, p_w, _ = _trace_limit(hip, sh, o, d, skip, never)
+    hitm = i_o >= 0
+    assert hitm.sum() > 1000
+    assert np.array_equal(t_o.view(np.uint32), t_w.view(np.uint32))
+    assert np.array_equal(i_o, i_w)
+    assert np.array_equal(p_o[hitm].view(np.uint32), p_w[hitm].view(np.uint32))
+
+
+@pytest.mark.parametrize("wide", ["0", "1"])
+@pytest.mark.parametrize("twin_light", [False, True])
+def test_twin_geometry_frames_are_the_same_bits(oracle, hip, twin_light, wide, monkeypatch):
+    """... and whole frames of such scenes with both walks: twin occluders, and twin EMITTERS - a shadow ray's limit is then
+    reached exactly by the twin of the emitter it aims at, and which of the two the reference meets first decides whether the
+    light is seen."""
+    monkeypatch.setenv("JADE_WIDE", wide)
+    hs, cfg = _twin_scene(twin_light)
+    p = B.params_from_config(cfg, spp=12)
+    p.width, p.height = 48, 40
+    q = type(p).from_buffer_copy(p)
+    q.walk = _abi.WALK_EARLY_EXIT
+    with hip.scene(hs) as sh, oracle.scene(hs) as so:
+        ref = sh.render(p)
+        early = sh.render(q)
+        r_o, b_o, st_o = so.render(p)
+    assert counters(ref[2]) == counters(st_o) and rel_l2(ref[0], r_o) <= 1e-4
+    assert_early_exit_equals_reference_walk(ref, early)

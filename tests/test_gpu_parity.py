@@ -37,6 +37,18 @@ def _render_both(oracle, hip, hs, params):
         r_o, b_o, st_o = so.render(params)
         r_h, b_h, st_h = sh.render(params)
         assert_early_exit_equals_reference_walk((r_h, b_h, st_h), sh.render(early))
+    # ... and with the wide form of k_trace's walk forced (by default only trees that do not fit the L2 get it)
+    import os
+    before = os.environ.get("JADE_WIDE")
+    os.environ["JADE_WIDE"] = "1"
+    try:
+        with hip.scene(hs) as sw:
+            assert_early_exit_equals_reference_walk((r_h, b_h, st_h), sw.render(early))
+    finally:
+        if before is None:
+            del os.environ["JADE_WIDE"]
+        else:
+            os.environ["JADE_WIDE"] = before
     return (r_o, b_o, st_o), (r_h, b_h, st_h)
 
 
@@ -220,10 +232,10 @@ def test_result_independent_of_shade_schedule(hip, monkeypatch):
         p = B.params_from_config(cfg, spp=spp)
         p.width, p.height = 40, 36
         ref = None
-        #            split fused batch packet budget
-        for v in (("1", "1", "1", "1", "32"), ("1", "1", "1", "0", "32"), ("1", "1", "1", "1", "3"), ("1", "1", "1", "1", "100000"),
-                  ("1", "0", "1", "1", "32"), ("0", "1", "1", "1", "32"), ("1", "1", "0", "1", "32")):
-            for key, val in zip(("JADE_SHADE_SPLIT", "JADE_FUSED", "JADE_BATCH", "JADE_LIGHT_PACKET", "JADE_PACKET_BUDGET"), v):
+        #            split fused batch packet budget wide (k_trace_wide for the walk=1 frame)
+        for v in (("1", "1", "1", "1", "32", "0"), ("1", "1", "1", "0", "32", "1"), ("1", "1", "1", "1", "3", "1"), ("1", "1", "1", "1", "100000", "0"),
+                  ("1", "0", "1", "1", "32", "1"), ("0", "1", "1", "1", "32", "0"), ("1", "1", "0", "1", "32", "1")):
+            for key, val in zip(("JADE_SHADE_SPLIT", "JADE_FUSED", "JADE_BATCH", "JADE_LIGHT_PACKET", "JADE_PACKET_BUDGET", "JADE_WIDE"), v):
                 monkeypatch.setenv(key, val)
             with hip.scene(hs) as sc:
                 rgb, bgr, st = sc.render(p)

@@ -1,0 +1,9 @@
+#!/bin/bash
+set -e
+mkdir -p gpurun_out/r03_w1
+O=gpurun_out/r03_w1
+timeout -k 10 900 python3 -m pytest tests/test_gpu_early_exit.py tests/test_gpu_parity.py -x -q -m gpu > $O/pytest.log 2>&1 || { tail -40 $O/pytest.log; exit 1; }
+tail -3 $O/pytest.log
+AB_ROUNDS=3 timeout -k 10 400 python3 tools/ab_variants.py "" _nowide > $O/ab_c3.log 2>&1 && cat $O/ab_c3.log
+AB_ROUNDS=3 AB_CLOSEUP=1 timeout -k 10 400 python3 tools/ab_variants.py "" _nowide > $O/ab_close.log 2>&1 && cat $O/ab_close.log
+AB_CONFIG=C5 AB_ROUNDS=2 timeout -k 10 400 python3 tools/ab_variants.py "" _nowide > $O/ab_c5.log 2>&1 && cat $O/ab_c5.log

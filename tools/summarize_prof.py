@@ -41,6 +41,7 @@ def reduce_dir(d):
     out = collections.defaultdict(lambda: {"dispatches": 0, "ns": 0, "counters": collections.defaultdict(float)})
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0]
+        k = {"k_trace_wide": "k_trace"}.get(k, k)  # the wide-walk form of k_trace (launched for renders with early exits) counts as k_trace
         if k not in KERNELS:
             continue
         o = out[k]
