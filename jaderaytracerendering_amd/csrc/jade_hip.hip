@@ -727,7 +727,10 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
                                                            uint32_t* spill, DevCounters* ctr, uint32_t chunk) {
   trace_body<false>(S, P, queue, qc, spill, ctr, chunk);
 }
-__global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace_wide(DevScene S, PathState P, const uint32_t* queue, QueueCtl* qc,
+#ifndef JADE_TRACE_WIDE_WAVES
+#define JADE_TRACE_WIDE_WAVES 4 /* 106 VGPRs, no scratch.  At 5 (96 VGPRs, 20 bytes of scratch) C5's k_trace takes 166.6 instead of 160.8 ms per step: the wide unit's four boxes want the registers more than the kernel wants the fifth wave */
+#endif
+__global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WIDE_WAVES) void k_trace_wide(DevScene S, PathState P, const uint32_t* queue, QueueCtl* qc,
                                                                 uint32_t* spill, DevCounters* ctr, uint32_t chunk) {
   trace_body<true>(S, P, queue, qc, spill, ctr, chunk);
 }
@@ -1478,6 +1481,7 @@ struct jade_scene {
   DevBuf b_state, b_sum, b_tiles, b_queue, b_active[2], b_ctl, b_ctr, b_spill, b_out_rgb, b_out_bgr, b_wavecnt;
   std::vector<int32_t> tile_ids;
   int trace_blocks = 0;
+  int trace_blocks_wide = 0;  // ... of k_trace_wide (fewer waves per SIMD)
   int light_blocks = 0;       // persistent grid of k_light
   int packet_blocks = 0;      // ... and of k_light_packet (0: the tree is too deep for the packet form)
   double packets_given_up = 0;  // share of the last fused pass's packets that were given up (reset by jade_render_begin)
@@ -1971,6 +1975,13 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
   if (s->tun.trace_blocks_per_cu >= 1 && s->tun.trace_blocks_per_cu < per_cu) per_cu = s->tun.trace_blocks_per_cu;  // development: occupancy sweeps
   if (s->tun.log_passes) fprintf(stderr, "[jade] k_trace: %d blocks of %d threads per CU, %d CUs\n", per_cu, JADE_TRACE_BLOCK, prop.multiProcessorCount);
   s->trace_blocks = prop.multiProcessorCount * per_cu;
+  {  // k_trace_wide keeps fewer waves: its own grid (the stack spill area is sized for the larger one)
+    int wide_cu = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&wide_cu, k_trace_wide, JADE_TRACE_BLOCK, 0);
+    if (wide_cu < 1) wide_cu = 1;
+    if (wide_cu > per_cu) wide_cu = per_cu;
+    s->trace_blocks_wide = prop.multiProcessorCount * wide_cu;
+  }
   int light_cu = 0;
   (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&light_cu, k_light, JADE_TRACE_BLOCK, 0);
   if (light_cu < 1) light_cu = 1;
@@ -2226,7 +2237,7 @@ static int run_passes(jade_scene* s, int64_t from_spp, uint32_t target_spp, bool
                            j ? qc + (j - 1) : (const QueueCtl*)nullptr, stop_below);
         cur ^= 1;
         HIP_TRY(hipEventRecord(s->ev_batch[2 * j], s->stream));
-        hipLaunchKernelGGL(trace_wide(s->dev, s->ps) ? k_trace_wide : k_trace, dim3((unsigned)s->trace_blocks), dim3(JADE_TRACE_BLOCK), 0, s->stream, s->dev, s->ps,
+        hipLaunchKernelGGL(trace_wide(s->dev, s->ps) ? k_trace_wide : k_trace, dim3((unsigned)(trace_wide(s->dev, s->ps) ? s->trace_blocks_wide : s->trace_blocks)), dim3(JADE_TRACE_BLOCK), 0, s->stream, s->dev, s->ps,
                            s->b_queue.as<uint32_t>(), qc + j, s->b_spill.as<uint32_t>(), s->b_ctr.as<DevCounters>(), 0u);
         HIP_TRY(hipEventRecord(s->ev_batch[2 * j + 1], s->stream));
       }
@@ -2390,7 +2401,7 @@ static int run_passes(jade_scene* s, int64_t from_spp, uint32_t target_spp, bool
                                         s->b_sortq.as<uint32_t>(), (size_t)n, 0u, 32u, s->stream));
       trace_queue = s->b_sortq.as<uint32_t>();
     }
-    hipLaunchKernelGGL(trace_wide(s->dev, s->ps) ? k_trace_wide : k_trace, dim3((unsigned)s->trace_blocks), dim3(JADE_TRACE_BLOCK), 0, s->stream, s->dev, s->ps,
+    hipLaunchKernelGGL(trace_wide(s->dev, s->ps) ? k_trace_wide : k_trace, dim3((unsigned)(trace_wide(s->dev, s->ps) ? s->trace_blocks_wide : s->trace_blocks)), dim3(JADE_TRACE_BLOCK), 0, s->stream, s->dev, s->ps,
                        trace_queue, qc, s->b_spill.as<uint32_t>(), s->b_ctr.as<DevCounters>(),
                        trace_chunk(s, host_ctl[0]));
     HIP_TRY(hipGetLastError());
@@ -2792,7 +2803,7 @@ static int trace_rays_impl(jade_scene* s, int32_t n, const float* origins, const
   HIP_TRY(ev0.create());
   HIP_TRY(ev1.create());
   HIP_TRY(hipEventRecord(ev0.e, s->stream));
-  hipLaunchKernelGGL(trace_wide(s->dev, P) ? k_trace_wide : k_trace, dim3((unsigned)s->trace_blocks), dim3(JADE_TRACE_BLOCK), 0, s->stream, s->dev, P, b_q.as<uint32_t>(),
+  hipLaunchKernelGGL(trace_wide(s->dev, P) ? k_trace_wide : k_trace, dim3((unsigned)(trace_wide(s->dev, P) ? s->trace_blocks_wide : s->trace_blocks)), dim3(JADE_TRACE_BLOCK), 0, s->stream, s->dev, P, b_q.as<uint32_t>(),
                      s->b_ctl.as<QueueCtl>(), b_spill.as<uint32_t>(), s->b_ctr.as<DevCounters>(), trace_chunk(s, (uint32_t)n));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(ev1.e, s->stream));

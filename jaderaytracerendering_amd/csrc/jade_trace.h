@@ -507,7 +507,7 @@ static __device__ __forceinline__ uint32_t node_decide4(const NodeRec4& nr, uint
   const uint32_t next = p1 ? n23 : n01;
   // pushes, in this order: other pair's farther, other pair's nearer, own pair's farther
   const uint32_t q0 = p1 ? f01 : f23, q1 = p1 ? n01 : n23, q2 = p1 ? f23 : f01;
-  const bool w0 = p1 ? fin01 : fin23, w1 = p1 ? nin01 : nin23, w2 = p1 ? fin23 : fin01;
+  const bool w0 = p1 ? fin01 : fin23, w1 = p1 ? nin01 : nin23, w2 = p1 ? fin23 : fin01;  // (in plain slot order instead: the same speed)
   const uint32_t dummy = stk.col + W_DUMMY * JADE_COL_STRIDE;
   const uint32_t lds_end = stk.col + JADE_LDS_STACK * JADE_COL_STRIDE;
   uint32_t sp = sp_io;
