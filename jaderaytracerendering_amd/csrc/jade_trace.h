@@ -497,36 +497,47 @@ static __device__ __forceinline__ uint32_t node_decide4(const NodeRec4& nr, uint
   const bool in0 = !is_leaf && d0 > 0, in1 = !is_leaf && v1 && d1 > 0, in2 = !is_leaf && d2 > 0, in3 = !is_leaf && v3 && d3 > 0;
   // the nearest of the boxes met is next; of the others, the pair it does not belong to goes onto the stack first (it comes off
   // last), its sibling last
-  const bool s01 = in1 && (!in0 || d1 < d0), s23 = in3 && (!in2 || d3 < d2);  // the nearer of each pair is its second member
+  // (decisions as and / or of lane masks: a `?:` between two of them is materialised in a register and compared again)
+  const bool s01 = in1 & (!in0 | (d1 < d0)), s23 = in3 & (!in2 | (d3 < d2));  // the nearer of each pair is its second member
   const float m01 = s01 ? d1 : d0, m23 = s23 ? d3 : d2;
-  const bool nin01 = in0 || in1, nin23 = in2 || in3;                           // a pair has a box that is met
-  const bool p1 = nin23 && (!nin01 || m23 < m01);                              // the nearest of all lies in pair 1
-  const bool any = nin01 || nin23;
+  const bool nin01 = in0 | in1, nin23 = in2 | in3;                            // a pair has a box that is met
+  const bool p1 = nin23 & (!nin01 | (m23 < m01));                             // the nearest of all lies in pair 1
+  const bool any = nin01 | nin23;
   const uint32_t n01 = s01 ? rf.y : rf.x, f01 = s01 ? rf.x : rf.y, n23 = s23 ? rf.w : rf.z, f23 = s23 ? rf.z : rf.w;
-  const bool fin01 = s01 ? in0 : in1, fin23 = s23 ? in2 : in3;  // the farther one of each pair is met too
+  const bool fin01 = in0 & in1, fin23 = in2 & in3;  // the farther one of a pair is met too = both are
   const uint32_t next = p1 ? n23 : n01;
-  // pushes, in this order: other pair's farther, other pair's nearer, own pair's farther
+  // pushes, in this order: other pair's farther, other pair's nearer, own pair's farther (in plain slot order instead: the same speed)
   const uint32_t q0 = p1 ? f01 : f23, q1 = p1 ? n01 : n23, q2 = p1 ? f23 : f01;
-  const bool w0 = p1 ? fin01 : fin23, w1 = p1 ? nin01 : nin23, w2 = p1 ? fin23 : fin01;  // (in plain slot order instead: the same speed)
+  const bool w0 = (p1 & fin01) | (!p1 & fin23), w1 = (p1 & nin01) | (!p1 & nin23), w2 = (p1 & fin23) | (!p1 & fin01);
   const uint32_t dummy = stk.col + W_DUMMY * JADE_COL_STRIDE;
   const uint32_t lds_end = stk.col + JADE_LDS_STACK * JADE_COL_STRIDE;
   uint32_t sp = sp_io;
-  lds_st((w0 && sp < lds_end) ? sp : dummy, q0);
-  if (w0 && sp >= lds_end) stk.spill[(size_t)((sp - lds_end) / JADE_COL_STRIDE) * stk.stride_spill] = q0;  // rare
-  sp += w0 ? JADE_COL_STRIDE : 0u;
-  lds_st((w1 && sp < lds_end) ? sp : dummy, q1);
-  if (w1 && sp >= lds_end) stk.spill[(size_t)((sp - lds_end) / JADE_COL_STRIDE) * stk.stride_spill] = q1;
-  sp += w1 ? JADE_COL_STRIDE : 0u;
-  lds_st((w2 && sp < lds_end) ? sp : dummy, q2);
-  if (w2 && sp >= lds_end) stk.spill[(size_t)((sp - lds_end) / JADE_COL_STRIDE) * stk.stride_spill] = q2;
-  sp += w2 ? JADE_COL_STRIDE : 0u;
+  const bool roomy = sp + 3u * JADE_COL_STRIDE <= lds_end;  // whatever this unit pushes stays in the LDS levels
+  if (__ballot((w0 | w1 | w2) & !roomy) == 0ull) {
+    lds_st(w0 ? sp : dummy, q0);
+    sp += w0 ? JADE_COL_STRIDE : 0u;
+    lds_st(w1 ? sp : dummy, q1);
+    sp += w1 ? JADE_COL_STRIDE : 0u;
+    lds_st(w2 ? sp : dummy, q2);
+    sp += w2 ? JADE_COL_STRIDE : 0u;
+  } else {  // rare: some lane's stack outgrows its LDS levels
+    lds_st((w0 && sp < lds_end) ? sp : dummy, q0);
+    if (w0 && sp >= lds_end) stk.spill[(size_t)((sp - lds_end) / JADE_COL_STRIDE) * stk.stride_spill] = q0;
+    sp += w0 ? JADE_COL_STRIDE : 0u;
+    lds_st((w1 && sp < lds_end) ? sp : dummy, q1);
+    if (w1 && sp >= lds_end) stk.spill[(size_t)((sp - lds_end) / JADE_COL_STRIDE) * stk.stride_spill] = q1;
+    sp += w1 ? JADE_COL_STRIDE : 0u;
+    lds_st((w2 && sp < lds_end) ? sp : dummy, q2);
+    if (w2 && sp >= lds_end) stk.spill[(size_t)((sp - lds_end) / JADE_COL_STRIDE) * stk.stride_spill] = q2;
+    sp += w2 ? JADE_COL_STRIDE : 0u;
+  }
   // ---- the nearest box is a leaf's: it is queued by this very unit and the walk goes on with what comes off the stack - which
   // may be what this unit has just pushed: a write and a read of the same LDS word in program order; a stack that has outgrown
   // its LDS levels leaves the leaf to the next unit instead
-  const bool leaf_now = !is_leaf && any && (int32_t)next < 0 && sp_io + 3u * JADE_COL_STRIDE <= lds_end;
+  const bool leaf_now = !is_leaf & any & ((int32_t)next < 0) & roomy;
   // ---- pop: a leaf that was queued by this unit, or a node none of whose boxes is met (such a lane pushed nothing)
-  const bool need_pop = is_leaf || !any || leaf_now;
-  const bool do_pop = need_pop && sp != stk.col;
+  const bool need_pop = is_leaf | !any | leaf_now;
+  const bool do_pop = need_pop & (sp != stk.col);
   const uint32_t sp1 = sp - JADE_COL_STRIDE;
   uint32_t top = lds_ld((do_pop && sp1 < lds_end) ? sp1 : dummy);
   asm volatile("" : "+v"(top));
@@ -955,7 +966,6 @@ struct WaveTrace {
     if (q_count <= JADE_WQ - 64 && nw > 0 && JADE_COST_TRI * (uint32_t)nw >= JADE_COST_NODE * nt) {
       const bool general = S.general_walk || __ballot(active && (int32_t)r.skipx < 0) != 0ull;  // per WAVE (node_core)
       const bool wide = WIDE && !general && __ballot(active && (r.skipx & JADE_FORCE_BINARY) != 0u) == 0ull;
-      (void)wide;  // (the profile build keeps to binary units)
 #pragma nounroll
       for (int rep = 0; rep < JADE_STEPS_PER_PICK; ++rep) {
         if (q_count > JADE_WQ - 64) break;
@@ -965,14 +975,22 @@ struct WaveTrace {
         {  // the walk unit in two laps: the record's fetch (until the data is in registers), then everything else
           PROF_COUNT(pr, PC_WALK_UNITS, 1);
           PROF_COUNT(pr, PC_WALK_LANES, (unsigned long long)__popcll(__ballot(go)));
-          NodeRec nr;
-          if (go) nr = node_fetch<JADE_TRACE_TOP_NODES>(r.cur, S, stk);
-          PROF_DRAIN();
-          PROF_LAP(pr, PL_WALK_LOAD);
-          if (general) {
-            if (go) leafv = node_decide<true, 0, TW_DUMMY>(nr, r.cur, r.sp, r.od, stk, true, vcnt, &r.inv);
+          if (WIDE && wide) {
+            NodeRec4 n4;
+            if (go) n4 = node_fetch4(r.cur, S, stk);
+            PROF_DRAIN();
+            PROF_LAP(pr, PL_WALK_LOAD);
+            if (go) leafv = node_decide4<TW_DUMMY>(n4, r.cur, r.sp, r.od, stk, vcnt, r.inv);
           } else {
-            if (go) leafv = node_decide<false, 0, TW_DUMMY>(nr, r.cur, r.sp, r.od, stk, true, vcnt, &r.inv);
+            NodeRec nr;
+            if (go) nr = node_fetch<JADE_TRACE_TOP_NODES>(r.cur, S, stk);
+            PROF_DRAIN();
+            PROF_LAP(pr, PL_WALK_LOAD);
+            if (general) {
+              if (go) leafv = node_decide<true, 0, TW_DUMMY>(nr, r.cur, r.sp, r.od, stk, true, vcnt, &r.inv);
+            } else {
+              if (go) leafv = node_decide<false, 0, TW_DUMMY>(nr, r.cur, r.sp, r.od, stk, true, vcnt, &r.inv);
+            }
           }
           leafv = (leafv & 15u) != 0 ? leafv : 0u;
           PROF_DRAIN();
