@@ -1274,9 +1274,15 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK) void k_packet_rays(DevScene S, in
   const bool exact = !(finite_f(1.0f / d.x) && finite_f(1.0f / d.y) && finite_f(1.0f / d.z)) || !finite_f(o.x) || !finite_f(o.y) || !finite_f(o.z);
   uint32_t vcnt = have ? 1u : 0u, tcnt = 0;
   PacketBest best;
-  if (S.general_walk || __ballot(have && exact) != 0ull) (void)packet_trace<true>(S, lds_addr_of(&lds_stack[w][0]), lane, have, o, d, skip[k], vcnt, tcnt, best, 0xffffffffu);
-  else (void)packet_trace<false>(S, lds_addr_of(&lds_stack[w][0]), lane, have, o, d, skip[k], vcnt, tcnt, best, 0xffffffffu);
-  if (have) {
+  bool whole;
+  if (S.general_walk || __ballot(have && exact) != 0ull) whole = packet_trace<true>(S, lds_addr_of(&lds_stack[w][0]), lane, have, o, d, skip[k], vcnt, tcnt, best, 0xffffffffu);
+  else whole = packet_trace<false>(S, lds_addr_of(&lds_stack[w][0]), lane, have, o, d, skip[k], vcnt, tcnt, best, 0xffffffffu);
+  if (have && !whole) {  // the packet was given up (no budget here: two leaves tied for some ray's best distance) - k_light_packet hands such rays to the wavefront passes
+    hit[i] = -3;
+    dist[i] = 0.0f;
+    point[3 * i] = point[3 * i + 1] = point[3 * i + 2] = 0.0f;
+    v_out[i] = t_out[i] = 0u;
+  } else if (have) {
     hit[i] = (int32_t)best.index;
     dist[i] = best.dist;
     point[3 * i] = best.point.x;

@@ -1113,14 +1113,13 @@ struct WaveTrace {
 //   * a node's record is read once per wave with scalar loads (constant address space: s_load, served by the scalar cache)
 //     and every lane whose ray entered that node tests both children with the record in SGPR operands - the same
 //     statements (slab2), so the same slab values, V counted per lane exactly as before;
-//   * a stack entry is {child reference, the lanes that entered it, the lanes for which it is the FAR child, depth}: the
-//     wave goes left first and pushes the right child whenever some lane entered it.  No per-lane stack, no leaf FIFO;
+//   * a stack entry is {child reference, the lanes that entered it}: the wave goes left first and pushes the right child
+//     whenever some lane entered it.  No per-lane stack, no leaf FIFO;
 //   * a leaf is tested by the lanes that entered it, the pair record again through scalar loads (pair_core unchanged);
-//   * the order a ray itself would have met its leaves in is kept as a KEY instead of a sequence number: bit (63 - depth)
-//     of `path` says whether the node of that depth on the current path is the far child (d1 < d2 decides, :835-848) for
-//     this lane's ray.  Two leaves a ray enters differ first at their lowest common ancestor, where one lies under the near
-//     child and the other under the far one; so among equal distances the smaller key is the leaf the reference met first,
-//     and within a leaf the index order and strict "<" decide as always.  Trees deeper than 63 take the per-lane form.
+//   * the order a ray itself would have met its leaves in is NOT kept (until round 3's last day it was, as a 64-bit key per lane
+//     with one bit per level - a fifth of a node visit's instructions, for the benefit of twin geometry): inside a leaf the index
+//     order and strict "<" decide as always, and when two LEAVES give a ray the same best distance the packet is given up - its
+//     rays go to the wavefront passes (k_trace), which walk them in the reference's order.
 // Everything wave-uniform lives in SGPRs; the stack is a small LDS array written by lane 0 and read as a broadcast.
 // ---------------------------------------------------------------------------------------------------------------
 #define JADE_PACKET_MAX_DEPTH 63
@@ -1131,36 +1130,30 @@ static __device__ __forceinline__ float4 ld_const_f4(jade_const_f4* p) {
   return make_float4(v.x, v.y, v.z, v.w);
 }
 struct PacketBest {
-  float dist;               // INF = no hit yet
-  unsigned long long key;   // the winning leaf's place in the ray's own order
-  uint32_t index;           // triangle index
+  float dist;      // INF = no hit yet
+  uint32_t leaf;   // the leaf the winning triangle sits in (byte offset of its first pair record)
+  uint32_t index;  // triangle index
   jvec3 point;
 };
 static __device__ __forceinline__ jade_const_f4* as_const_f4(const void* base, uint32_t byte_off) {
   return reinterpret_cast<jade_const_f4*>(reinterpret_cast<__SIZE_TYPE__>(reinterpret_cast<const char*>(base) + byte_off));
 }
-// stack entry k of the wave at LDS byte address stack + 32 k: {ref, depth, lanes lo, lanes hi, far lo, far hi, -, -}
-static __device__ __forceinline__ void packet_push(uint32_t stack, uint32_t sp, int lane, uint32_t ref, uint32_t depth, unsigned long long lanes,
-                                                   unsigned long long far) {
+// stack entry k of the wave at LDS byte address stack + 32 k: {ref, -, lanes lo, lanes hi, ...}
+static __device__ __forceinline__ void packet_push(uint32_t stack, uint32_t sp, int lane, uint32_t ref, unsigned long long lanes) {
   if (lane == 0) {
     const uint32_t a = stack + 32u * sp;
-    lds_st64(a, ref, depth);
+    lds_st64(a, ref, 0u);
     lds_st64(a + 8u, (uint32_t)lanes, (uint32_t)(lanes >> 32));
-    lds_st64(a + 16u, (uint32_t)far, (uint32_t)(far >> 32));
   }
 }
-static __device__ __forceinline__ void packet_pop(uint32_t stack, uint32_t sp, uint32_t& ref, uint32_t& depth, unsigned long long& lanes,
-                                                  unsigned long long& far) {
+static __device__ __forceinline__ void packet_pop(uint32_t stack, uint32_t sp, uint32_t& ref, unsigned long long& lanes) {
   const uint32_t a = stack + 32u * sp;  // the same address in every lane: a broadcast read
-  uint32_t r, d, l0, l1, f0, f1;
+  uint32_t r, d, l0, l1;
   lds_ld64(a, r, d);
   lds_ld64(a + 8u, l0, l1);
-  lds_ld64(a + 16u, f0, f1);
   // (readfirstlane returns an int: through uint32_t, or the low word sign-extends into the lanes 32-63)
   ref = (uint32_t)__builtin_amdgcn_readfirstlane(r);
-  depth = (uint32_t)__builtin_amdgcn_readfirstlane(d);
   lanes = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(l0) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(l1) << 32);
-  far = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(f0) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(f1) << 32);
 }
 
 // hitBVH (PathTrace.cu:795-859) for the rays of the lanes with `active`, all lanes of the wave taking part in the control
@@ -1182,25 +1175,22 @@ static __device__ __forceinline__ bool packet_trace(const DevScene& S, uint32_t 
   od.c = f2{dn.y, dn.z};
   const uint32_t skipu = skip < 0 ? 0x7fffffffu : (uint32_t)skip;
   best.dist = JADE_INF_F;
-  best.key = 0ull;
+  best.leaf = 0u;
   best.index = 0xffffffffu;
   best.point = jv(0, 0, 0);
-  unsigned long long path = 0ull;
   const unsigned long long me = 1ull << lane;
-  uint32_t cur = S.root_ref, depth = 0, sp = 0;
-  unsigned long long lanes = __ballot(active), far = 0ull;
+  uint32_t cur = S.root_ref, sp = 0;
+  unsigned long long lanes = __ballot(active);
   if (lanes == 0ull) return true;
   uint32_t records = 0;
+  bool tie = false;
   for (;;) {
     if (records > budget) return false;
     const bool in = (lanes & me) != 0ull;
-    // this node's bit of the path: set for the lanes it is the far child for
-    const unsigned long long bit = 1ull << (63u - depth);
-    if (in) path = (far & me) ? (path | bit) : (path & ~bit);
     if ((int32_t)cur < 0) {
       // ---- a leaf: its pair records, one after the other, for the lanes that entered it (hitArray, :776-792)
-      const unsigned long long key = path & ~(bit - 1ull);  // (levels below this leaf hold bits of paths walked before)
-      uint32_t off = cur & 0x7ffffff0u;
+      const uint32_t leaf_id = cur & 0x7ffffff0u;
+      uint32_t off = leaf_id;
       records += cur & 15u;
       for (uint32_t n = cur & 15u; n != 0u; --n, off += 80u) {
         jade_const_f4* t = as_const_f4(S.tverts, off);
@@ -1220,16 +1210,22 @@ static __device__ __forceinline__ bool packet_trace(const DevScene& S, uint32_t 
             if (k == 0 ? in_a : in_b) {
               float dist;
               jvec3 P;
-              if (pair_hit(tv, k, od, &dist, &P) && (dist < best.dist || (dist == best.dist && key < best.key))) {
-                best.dist = dist;
-                best.key = key;
-                best.index = idx_a + (uint32_t)k;
-                best.point = P;
+              if (pair_hit(tv, k, od, &dist, &P)) {
+                // strict "<" (:787): inside a leaf the earlier index keeps an equal distance.  Two LEAVES at the same distance: the
+                // one the ray itself would have met first wins, and a packet does not know which that is - it is given up (below)
+                tie = tie || (dist == best.dist && best.leaf != leaf_id);
+                if (dist < best.dist) {
+                  best.dist = dist;
+                  best.leaf = leaf_id;
+                  best.index = idx_a + (uint32_t)k;
+                  best.point = P;
+                }
               }
             }
           }
         }
       }
+      if (__ballot(tie) != 0ull) return false;  // (twin geometry; the wavefront passes walk these rays in the reference's order)
     } else {
       // ---- an internal node: both children's boxes from its record (hitAABB x 2, :825-832)
       records += 1u;
@@ -1249,31 +1245,26 @@ static __device__ __forceinline__ bool packet_trace(const DevScene& S, uint32_t 
         in1 = in && d1 > 0;
         in2 = in && d2 > 0;
       }
-      const bool both = in1 && in2, first = d1 < d2;  // near child first, :835-848: the far one is the other
       const unsigned long long m1 = __ballot(in1), m2 = __ballot(in2);
-      const unsigned long long f1 = __ballot(both && !first), f2m = __ballot(both && first);
-      depth += 1u;
       if (m1 != 0ull) {
         if (m2 != 0ull) {
-          packet_push(stack, sp, lane, right, depth, m2, f2m);
+          packet_push(stack, sp, lane, right, m2);
           sp += 1u;
         }
         cur = left;
         lanes = m1;
-        far = f1;
         continue;
       }
       if (m2 != 0ull) {
         cur = right;
         lanes = m2;
-        far = f2m;
         continue;
       }
     }
     // ---- nothing below: the next deferred child
     if (sp == 0u) break;
     sp -= 1u;
-    packet_pop(stack, sp, cur, depth, lanes, far);
+    packet_pop(stack, sp, cur, lanes);
   }
   return true;
 }

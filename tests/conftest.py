@@ -77,16 +77,17 @@ def counters(st):
 WALK_KEYS = ("nodes_visited", "tris_tested")  # what jade_render_params.walk may change (jade_rt.h, JADE_WALK_*)
 
 
-def assert_early_exit_equals_reference_walk(ref, early):
+def assert_early_exit_equals_reference_walk(ref, early, fewer=True):
     """(rgb, bgr, stats) of one frame rendered with JADE_WALK_REFERENCE and with JADE_WALK_EARLY_EXIT: every float of the
-    radiance and every byte the same, every ray / sample / vertex count the same; node records and triangle tests fewer."""
+    radiance and every byte the same, every ray / sample / vertex count the same; node records and triangle tests fewer
+    (fewer=False: a scene made of ties, whose rays the wide walk has to walk a second time)."""
     (r0, b0, s0), (r1, b1, s1) = ref, early
     assert np.array_equal(r0.view(np.uint32), r1.view(np.uint32)), "radiance differs between the two walks"
     assert np.array_equal(b0, b1)
     c0, c1 = counters(s0), counters(s1)
     assert {k: v for k, v in c0.items() if k not in WALK_KEYS} == {k: v for k, v in c1.items() if k not in WALK_KEYS}
     for k in WALK_KEYS:
-        assert c1[k] <= c0[k], k
+        assert not fewer or c1[k] <= c0[k], k
 
 
 @pytest.fixture(scope="session")

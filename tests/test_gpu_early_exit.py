@@ -171,17 +171,17 @@ def test_unknown_walk_is_refused(hip):
 
 
 def _twin_scene(twin_light=False):
-    """Every triangle of the ball exists twice at the same place (and, with twin_light, the light too): nearly every hit has a
-    twin at exactly the same distance, most of them in another leaf."""
+    """Every triangle of the ball exists twelve times at the same place (and, with twin_light, a light too) while a leaf holds
+    eight triangles: every hit on them has twins at exactly the same distance in OTHER leaves."""
     from jaderaytracerendering_amd import host as H
     b = J.SceneBuilder()
     cfg = b.config("tinyjade" if twin_light else "tiny")
     mat = H.material(brdf=(0.5,) * 3)
-    for _ in range(2):
-        b.add_proc("geodesic", 3, mat, H.transform_matrix(trans=(0.1, -1.2, 1.0), scale=(1.1, 1.1, 1.1)))
+    for _ in range(12):
+        b.add_proc("geodesic", 1, mat, H.transform_matrix(trans=(0.1, -1.2, 1.0), scale=(1.1, 1.1, 1.1)))
     if twin_light:
         light = H.material(emissive=(30.0,) * 3, brdf=(0.3,) * 3)
-        for _ in range(2):
+        for _ in range(12):
             b.add_proc("geodesic", 0, light, H.transform_matrix(trans=(0.4, 1.0, 1.3), scale=(0.3, 0.3, 0.3)))
     b.set_env_sky(16, 8)
     return b.build(), cfg
@@ -230,4 +230,4 @@ def test_twin_geometry_frames_are_the_same_bits(oracle, hip, twin_light, wide, m
         early = sh.render(q)
         r_o, b_o, st_o = so.render(p)
     assert counters(ref[2]) == counters(st_o) and rel_l2(ref[0], r_o) <= 1e-4
-    assert_early_exit_equals_reference_walk(ref, early)
+    assert_early_exit_equals_reference_walk(ref, early, fewer=False)  # (a ray with a tie is walked twice by the wide form)
