@@ -145,13 +145,16 @@ struct PathState {
                         // order by k_light (coalesced); for k_shade, whose records are scattered, one sector instead of three
   int32_t sum_lanes;    // partial sums kept per pixel: min(JADE_SAMPLE_LANES, announced spp rounded up to a power of two) >= rpp
   float* sum;           // [3][sum_lanes * npx] partial radiance sums per (lane, pixel); sample s adds into lane s % JADE_SAMPLE_LANES
-  // The context of a path in flight, five float4 per record (only k_shade and a record k_light parks touch it; what every
-  // pass of every record reads - rng, done, stage - stays in planes):
-  //   {thr.xyz, obj} {acc.xyz, auxi} {le.xyz, src.x} {src.y, src.z, out.x, out.y} {out.z, aux.xyz}
+  // The context of a path in flight, four float4 = one aligned 64-B sector per record (only k_shade and a record k_light parks
+  // touch it; what every pass of every record reads - rng, done, stage - is the header):
+  //   {thr.xyz, obj} {acc.xyz, out.z} {le.xyz, src.x} {src.y, src.z, out.x, out.y}
   // thr = throughput (product of pushed rates), acc = radiance gathered along the current path, le = emission at the
-  // primary hit, obj = current vertex: triangle index, src = its position, out = direction back toward the previous
-  // vertex, aux = BSSRDF profile / refraction attenuation, auxi = refraction: iteration counter.
+  // primary hit, obj = current vertex: triangle index, src = its position, out = direction back toward the previous vertex.
+  // Until round 3's last day the record was five float4 (80 B: two sectors, read and written at every visit); the fifth -
+  // aux = BSSRDF profile / refraction attenuation, auxi = refraction: iteration counter - is an array of its own now, which
+  // only the BSSRDF and refraction stages touch.
   float4* ctx;
+  float4* aux;          // [npix] {aux.xyz, auxi}
   float eye[3];         // origin of every camera ray (skip == JADE_SKIP_CAMERA): not stored per record
   float4* orgs;         // [npix] {origin shared by this record's pending rays, source triangle of those rays (int bits)}
   // Ray slots, two float4 per slot and a record's slots side by side: slot[(p * nslots + k) * 2] = {direction, hit (int bits:

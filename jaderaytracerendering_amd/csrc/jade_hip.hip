@@ -233,8 +233,8 @@ static __device__ __forceinline__ void shade_record(const DevScene& S, const Pat
       // path_push thr is 1 and acc 0 (only path_push changes them, and it counts depth up); a
       // mirror ray in flight needs neither the vertex it left nor, at depth 0, a stored Le
       // (it is the emissive of the triangle still in obj).
-      const float4* cx = P.ctx + (size_t)p * 5;
-      const float4 b0 = cx[0], b1 = cx[1], b2 = cx[2], b3 = cx[3], b4 = cx[4];
+      const float4* cx = P.ctx + (size_t)p * 4;
+      const float4 b0 = cx[0], b1 = cx[1], b2 = cx[2], b3 = cx[3];
       c.obj = __float_as_int(b0.w);
       if (c.depth != 0) {
         c.thr = jv(b0.x, b0.y, b0.z);
@@ -244,7 +244,7 @@ static __device__ __forceinline__ void shade_record(const DevScene& S, const Pat
       else c.le = jv(b2.x, b2.y, b2.z);
       if (st != ST_MIRROR) {
         c.src = jv(b2.w, b3.x, b3.y);
-        c.out = jv(b3.z, b3.w, b4.x);
+        c.out = jv(b3.z, b3.w, b1.w);
       }
     }
     uint32_t done = done0;
@@ -349,14 +349,12 @@ static __device__ __forceinline__ void shade_record(const DevScene& S, const Pat
     }
     P.hdr[p] = make_uint4(c.rng, done, st | (c.depth << 8) | (c.flags << 16), 0u);
     if ((st >= ST_DIFFUSE && st <= ST_REFRACT_EXIT) || st == ST_VERTEX) {
-      // (aux and auxi - words 17-19 and 7 - are begin_bounce's and consume's: written through Px while this record was shaded)
-      float4* cx = P.ctx + (size_t)p * 5;
-      float* cf = reinterpret_cast<float*>(cx);
-      cf[0] = c.thr.x; cf[1] = c.thr.y; cf[2] = c.thr.z; cf[3] = __int_as_float(c.obj);
-      cf[4] = c.acc.x; cf[5] = c.acc.y; cf[6] = c.acc.z;
+      // (aux and auxi - P.aux - are begin_bounce's and consume's: written through Px while this record was shaded)
+      float4* cx = P.ctx + (size_t)p * 4;
+      cx[0] = make_float4(c.thr.x, c.thr.y, c.thr.z, __int_as_float(c.obj));
+      cx[1] = make_float4(c.acc.x, c.acc.y, c.acc.z, c.out.z);
       cx[2] = make_float4(c.le.x, c.le.y, c.le.z, c.src.x);
       cx[3] = make_float4(c.src.y, c.src.z, c.out.x, c.out.y);
-      cf[16] = c.out.z;
     }
   }
   st_out = st;
@@ -964,13 +962,11 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_LIGHT_WAVES) void k_light(De
     if (have && st != ST_INVALID && !untouched) {  // (a carried-over record was not touched)
       P.hdr[p] = make_uint4(c.rng, done, st == ST_VERTEX ? ST_VERTEX | (c.depth << 8) | (c.flags << 16) : (uint32_t)ST_IDLE, 0u);
       if (st == ST_VERTEX) {  // parked: the path context, as shade_record stores it for this stage
-        float4* cx = P.ctx + (size_t)p * 5;
-        float* cf = reinterpret_cast<float*>(cx);
-        cf[0] = c.thr.x; cf[1] = c.thr.y; cf[2] = c.thr.z; cf[3] = __int_as_float(c.obj);
-        cf[4] = c.acc.x; cf[5] = c.acc.y; cf[6] = c.acc.z;
+        float4* cx = P.ctx + (size_t)p * 4;
+        cx[0] = make_float4(c.thr.x, c.thr.y, c.thr.z, __int_as_float(c.obj));
+        cx[1] = make_float4(c.acc.x, c.acc.y, c.acc.z, c.out.z);
         cx[2] = make_float4(c.le.x, c.le.y, c.le.z, c.src.x);
         cx[3] = make_float4(c.src.y, c.src.z, c.out.x, c.out.y);
-        cf[16] = c.out.z;
       }
     }
     // ---- hand-over: append to this wave's region
@@ -1211,13 +1207,11 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_PACKET_WAVES) void k_light_p
     if (have && st != ST_INVALID && !untouched) {  // (a carried-over record was not touched)
       P.hdr[p] = make_uint4(c.rng, done, st == ST_VERTEX ? ST_VERTEX | (c.depth << 8) | (c.flags << 16) : (uint32_t)ST_IDLE, 0u);
       if (st == ST_VERTEX) {  // parked: the path context, as shade_record stores it for this stage
-        float4* cx = P.ctx + (size_t)p * 5;
-        float* cf = reinterpret_cast<float*>(cx);
-        cf[0] = c.thr.x; cf[1] = c.thr.y; cf[2] = c.thr.z; cf[3] = __int_as_float(c.obj);
-        cf[4] = c.acc.x; cf[5] = c.acc.y; cf[6] = c.acc.z;
+        float4* cx = P.ctx + (size_t)p * 4;
+        cx[0] = make_float4(c.thr.x, c.thr.y, c.thr.z, __int_as_float(c.obj));
+        cx[1] = make_float4(c.acc.x, c.acc.y, c.acc.z, c.out.z);
         cx[2] = make_float4(c.le.x, c.le.y, c.le.z, c.src.x);
         cx[3] = make_float4(c.src.y, c.src.z, c.out.x, c.out.y);
-        cf[16] = c.out.z;
       }
     }
     // ---- hand-over: append to this wave's region
@@ -2017,7 +2011,7 @@ static int setup_state(jade_scene* s, int npx, int rpp, int nslots, int sum_lane
   size_t words = 0;
   auto take = [&](size_t n) { size_t o = words; words += (n + 63) & ~(size_t)63; return o; };
   const size_t N = (size_t)npix, K = (size_t)nslots;
-  size_t o_hdr = take(4 * N), o_ctx = take(20 * N), o_orgs = take(4 * N), o_slot = take(8 * K * N);
+  size_t o_hdr = take(4 * N), o_ctx = take(16 * N), o_aux = take(4 * N), o_orgs = take(4 * N), o_slot = take(8 * K * N);
   HIP_TRY(s->b_state.alloc(words * 4));
   HIP_TRY(hipMemsetAsync(s->b_state.p, 0, words * 4, s->stream));
   // the partial sums are an allocation of their own: they grow if steps add more samples than were announced (grow_sums)
@@ -2038,7 +2032,7 @@ static int setup_state(jade_scene* s, int npx, int rpp, int nslots, int sum_lane
   P.nslots = nslots;
   P.hdr = (uint4*)(b + o_hdr);
   P.sum_lanes = sum_lanes;
-  P.sum = s->b_sum.as<float>(); P.ctx = (float4*)(b + o_ctx); P.orgs = (float4*)(b + o_orgs);
+  P.sum = s->b_sum.as<float>(); P.ctx = (float4*)(b + o_ctx); P.aux = (float4*)(b + o_aux); P.orgs = (float4*)(b + o_orgs);
   P.slot = (float4*)(b + o_slot);
   HIP_TRY(s->b_queue.alloc(K * N * 4));
   // b_active[0] doubles as k_light's per-wave hand-over regions: up to 64 records of slack per wave of its grid

@@ -169,17 +169,17 @@ struct Px {
     return jv(v.x, v.y, v.z);
   }
   __device__ int skip() const { return reinterpret_cast<const int*>(P.orgs + p)[3]; }
-  // aux / auxi of the path context (jade_device.h): words 17-19 and 7 of the record's five float4
+  // aux / auxi of the path (jade_device.h, PathState.aux): a float4 of their own, touched by the BSSRDF and refraction stages only
   __device__ jvec3 aux() const {
-    const float* f = reinterpret_cast<const float*>(P.ctx + (size_t)p * 5);
-    return jv(f[17], f[18], f[19]);
+    const float4 v = P.aux[p];
+    return jv(v.x, v.y, v.z);
   }
   __device__ void set_aux(jvec3 v) const {
-    float* f = reinterpret_cast<float*>(P.ctx + (size_t)p * 5);
-    f[17] = v.x; f[18] = v.y; f[19] = v.z;
+    float* f = reinterpret_cast<float*>(P.aux + p);
+    f[0] = v.x; f[1] = v.y; f[2] = v.z;
   }
-  __device__ int auxi() const { return reinterpret_cast<const int*>(P.ctx + (size_t)p * 5)[7]; }
-  __device__ void set_auxi(int v) const { reinterpret_cast<int*>(P.ctx + (size_t)p * 5)[7] = v; }
+  __device__ int auxi() const { return reinterpret_cast<const int*>(P.aux + p)[3]; }
+  __device__ void set_auxi(int v) const { reinterpret_cast<int*>(P.aux + p)[3] = v; }
 };
 
 // The same view held in registers: k_light traces a record's single ray (camera or mirror) in the kernel that shades
