@@ -79,6 +79,7 @@ def parse():
     ap.add_argument("--bvh-leaf", type=int, default=0, help="triangles per leaf for the GPU builders (0: 8 for lbvh as in the reference, 3 for ploc)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL) for real runs; gloo rehearses the multi-rank flow with every rank on one GPU")
+    ap.add_argument("--virtual-rank", type=int, default=0, help="with --virtual-ranks: which rank's share of the tiles (default 0)")
     ap.add_argument("--virtual-ranks", type=int, default=0,
                     help="development: render rank 0's share of a V-GPU run on this one GPU (partition and spp as at N=V)")
     ap.add_argument("--cpu-spp", type=int, default=8, help="oracle sample: spp over the full frame")
@@ -174,7 +175,7 @@ def main():
     height = args.height or cfg.height
     part_world, part_rank = world, rank
     if args.virtual_ranks > 1 and world == 1:
-        part_world, part_rank = args.virtual_ranks, 0
+        part_world, part_rank = args.virtual_ranks, args.virtual_rank % args.virtual_ranks
     spp_step = args.spp_per_step * part_world  # weak scaling: fixed work per GPU per step
     walk = _abi.WALK_REFERENCE if args.reference_walk else _abi.WALK_EARLY_EXIT
     params = B.make_params(width, height, spp_step, list(cfg.eye), list(cfg.camera), tile_rank=part_rank,
