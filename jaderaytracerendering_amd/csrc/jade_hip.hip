@@ -13,7 +13,10 @@
 //                   compacted queue (wave prefix sums + one 64-bit atomic per block)
 //   k_ray_keys      (+ rocPRIM pairs sort) orders the queue for scenes whose tree does not fit the L2
 //   k_trace         persistent workgroups claim chunks of the queue and run the BVH traversal (jade_trace.h) - the
-//                   dominant kernel
+//                   dominant kernel.  With jade_render_params.walk = JADE_WALK_EARLY_EXIT a shadow / environment-visibility
+//                   walk ends at the first recorded hit that settles what the integrator asks of it (the limit k_shade puts
+//                   beside the ray); k_trace_wide: the same kernel visiting four grandchildren per node, launched instead for
+//                   such renders on trees that do not fit the L2
 //   k_resolve       adds the partial sums; mean, ACES, gamma, BGR8 pack (PathTrace.cu:1457-1473)
 //   k_arm / k_shade_lean  list the records with work / shade light samples over all records: the schedules without the
 //                   fused pass (flushes, JADE_FUSED=0)
