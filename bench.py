@@ -365,6 +365,7 @@ def main():
             },
             # the same steps with every query walked to the end as the reference does (null with --reference-walk / --no-extras)
             "reference_walk": ref_walk,
+            "value_reference_walk": ref_walk["value"] if ref_walk else (None if not args.reference_walk else rays_all / dt / 1e6),
             "virtual_ranks": part_world if part_world != world else None,
             "rehearsal_all_ranks_on_one_gpu": True if rehearsal else None,
             "rays": rays_all,

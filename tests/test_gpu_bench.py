@@ -49,7 +49,7 @@ def test_bench_json_contract():
     # the timed region runs with early exits (jade_rt.h, JADE_WALK_EARLY_EXIT); the same steps with the reference's walk are
     # measured beside it, and the algorithmic bytes are those of the reference's walk, not of what was read
     rw = d["reference_walk"]
-    assert d["config"]["walk"] == "early_exit" and rw["value"] > 0 and rw["steps"] == 2
+    assert d["config"]["walk"] == "early_exit" and rw["value"] > 0 and rw["steps"] == 2 and d["value_reference_walk"] == rw["value"]
     assert rw["nodes_per_ray_k_trace"] >= kt["nodes_per_ray"] and rw["tris_per_ray_k_trace"] >= kt["tris_per_ray"]
     assert abs(kt["algorithmic_bytes_per_ray"] - (40 * rw["nodes_per_ray_k_trace"] + 36 * rw["tris_per_ray_k_trace"])) < 1e-6 * kt["algorithmic_bytes_per_ray"]
     # the frame the run rendered, against the oracle on a few tiles at the full sample count
