@@ -41,7 +41,13 @@ $(LIBDIR)/libjade_hip_stack4.so: $(HIP_SRC) $(HIP_HDR)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) -DJADE_LDS_STACK=4 $(HIPFLAGS) -shared -o $@ $(HIP_SRC) -ldl
 
-hipvariants: $(LIBDIR)/libjade_hip_stack4.so
+# test-only build: the jade_debug_* entry points (raw rays with a limit, packets, shadow limits) that the piece-by-piece
+# GPU tests call; libjade_hip.so exports exactly what include/jade_rt.h + jade_bvh.h declare
+$(LIBDIR)/libjade_hip_debug.so: $(HIP_SRC) $(HIP_HDR)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) -DJADE_DEBUG_EXPORTS=1 $(HIPFLAGS) -shared -o $@ $(HIP_SRC) -ldl
+
+hipvariants: $(LIBDIR)/libjade_hip_stack4.so $(LIBDIR)/libjade_hip_debug.so
 
 # development A/B builds (tools/ab_variants.py): make variant NAME=_b256 DEFS="-DJADE_TRACE_BLOCK=256 -DJADE_LDS_TOP_NODES=0"
 variant: $(HIP_SRC) $(HIP_HDR)

@@ -85,6 +85,11 @@ def parse():
     ap.add_argument("--cpu-spp", type=int, default=8, help="oracle sample: spp over the full frame")
     ap.add_argument("--max-state-gb", type=float, default=0.0, help="jade_render_params.max_state_bytes: device memory for path records + partial sums (0 = the default, 60 %% of what is free)")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle spot check of the rendered frame")
+    ap.add_argument("--walk", default=None, choices=["reference", "early_exit", "cached"],
+                    help="jade_render_params.walk in the timed region.  early_exit (the default): JADE_WALK_EARLY_EXIT; cached: "
+                         "JADE_WALK_EARLY_EXIT_CACHED - early exits, and yes/no queries first look where earlier ones found their answer (the same "
+                         "frame bit for bit; measured slower on C3, DESIGN.md 3.3d); reference: every query walks what the reference walks")
+    ap.add_argument("--side-steps", type=int, default=0, help="steps of the side runs with the other walks (0 = as many as --steps, with --warmup warm-up steps)")
     ap.add_argument("--reference-walk", action="store_true",
                     help="jade_render_params.walk = JADE_WALK_REFERENCE in the timed region: every query walks what the reference walks "
                          "(the default, JADE_WALK_EARLY_EXIT, ends shadow / environment-visibility walks at the hit that settles them: the same frame, bit for bit)")
@@ -103,6 +108,33 @@ def spawn_ranks(n):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
+
+
+def prepare_rank_env(world):
+    """What a rank needs in its environment BEFORE torch / HIP are loaded, however it was started - by spawn_ranks above or by
+    the driver's own `python -m torch.distributed.run ... bench.py` (which sets nothing of this).  The pool's host driver only
+    supports dmabuf IPC: without HSA_ENABLE_IPC_MODE_LEGACY=0 RCCL's bootstrap fails with `hipIpcGetMemHandle: invalid argument`
+    on the first multi-rank launch.  setdefault: an operator's explicit value wins."""
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+
+
+def rank_plumbing(args, rank, local_rank, world):
+    """The rank / tile / sample plumbing of main(), as data (no torch, no GPU touched): which tiles this rank owns under the
+    (tx + ty) % N deal (the same distributed.owned_tile_ids the gather assembles the frame with) and how many samples a step
+    adds.  tests/test_bench_host.py starts bench.py both ways - as the driver does, under torch.distributed.run, and
+    self-spawned - and compares what the ranks report."""
+    import hashlib
+    from jaderaytracerendering_amd import distributed as D
+    width, height = (3840, 2160) if args.config == "C5" else (1920, 1080)
+    width, height = args.width or width, args.height or height
+    owned = [int(t) for t in D.owned_tile_ids(width, height, rank, world)]
+    return {"rank": rank, "local_rank": local_rank, "world": world, "gpus": args.gpus, "spp_per_step": args.spp_per_step * world,
+            "steps": args.steps, "warmup": args.warmup, "dist_backend": args.dist_backend, "width": width, "height": height,
+            "owned_tiles": len(owned), "owned_tiles_sha": hashlib.sha256(repr(owned).encode()).hexdigest()[:16], "first_tiles": owned[:4],
+            "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), "MASTER_ADDR": os.environ.get("MASTER_ADDR"),
+            "torch_loaded": "torch" in sys.modules}
 
 
 def profile_json(name):
@@ -138,6 +170,10 @@ def main():
     if world == 1 and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus))
     args.gpus = world
+    prepare_rank_env(world)
+    if os.environ.get("JADE_BENCH_PLUMBING_ONLY"):   # tests/test_bench_host.py: what a rank started by the driver's launcher sees, no GPU touched
+        print(json.dumps(rank_plumbing(args, rank, local_rank, world)), flush=True)
+        return
 
     import torch
     import torch.distributed as dist
@@ -177,7 +213,8 @@ def main():
     if args.virtual_ranks > 1 and world == 1:
         part_world, part_rank = args.virtual_ranks, args.virtual_rank % args.virtual_ranks
     spp_step = args.spp_per_step * part_world  # weak scaling: fixed work per GPU per step
-    walk = _abi.WALK_REFERENCE if args.reference_walk else _abi.WALK_EARLY_EXIT
+    walk_name = "reference" if args.reference_walk else (args.walk or "early_exit")
+    walk = {"reference": _abi.WALK_REFERENCE, "early_exit": _abi.WALK_EARLY_EXIT, "cached": _abi.WALK_EARLY_EXIT_CACHED}[walk_name]
     params = B.make_params(width, height, spp_step, list(cfg.eye), list(cfg.camera), tile_rank=part_rank,
                            tile_nranks=part_world, device_id=local_rank, walk=walk)
     if rehearsal and world > 1:  # ranks share one GPU: each may hold its share of the memory, not 60 % of what is free
@@ -246,37 +283,47 @@ def main():
     parity_frame = None
     if rank == 0 and world == 1 and part_world == 1 and not args.no_cpu_baseline and not args.no_parity_check:
         parity_frame = scene.resolve()   # (rgb, bgr8) of the frame the timed region finished: host copies, outside the clock
-    # The same steps with the reference's walk, outside the timed region (one warm-up step, two timed): what the early exits are
-    # worth, and the V / T per ray of the REFERENCE traversal that SURVEY 8(d)'s algorithmic bytes are defined by.
-    ref_walk = None
-    if rank == 0 and world == 1 and walk == _abi.WALK_EARLY_EXIT and not args.no_extras:
+    # The same steps with the other walks, outside the timed region and with the SAME step and warm-up counts (a side run
+    # of two steps weighs its flush differently): the reference's walk - what the early exits are worth, and the V / T per ray of the
+    # REFERENCE traversal that SURVEY 8(d)'s algorithmic bytes are defined by - and early exits without the occluder cache.
+    def side_run(side_walk, what):
         rp = type(params).from_buffer_copy(params)
-        rp.walk = _abi.WALK_REFERENCE
-        rp.spp = spp_step * 3
+        rp.walk = side_walk
+        k_steps = args.side_steps or args.steps
+        rp.spp = spp_step * (args.warmup + k_steps)
         scene.begin(rp)
         rw = _abi.Stats()
-        scene.step(spp_step, rw)
+        for _ in range(args.warmup):
+            scene.step(spp_step, rw)
+        scene.flush(rw)
         rs = _abi.Stats()
         torch.cuda.synchronize()
         r0 = time.perf_counter()
-        scene.step(spp_step, rs)
-        scene.step(spp_step, rs)
-        scene.flush(rs)   # inside the clock, as in the timed region above (it weighs twice as much over two steps as over four)
+        for _ in range(k_steps):
+            scene.step(spp_step, rs)
+        scene.flush(rs)   # inside the clock, as in the timed region above
         rdt = time.perf_counter() - r0
         r_rays = float(rs.rays_primary + rs.rays_secondary)
-        r_trace = max(float(r_rays - rs.rays_inline), 1.0)
-        ref_walk = {"value": r_rays / rdt / 1e6, "unit": "Mray/s", "ms_per_step": rdt / 2 * 1e3, "steps": 2, "warmup": 1,
-                    "k_trace_ms_per_step": rs.trace_ms / 2, "k_trace_Mray_per_s": r_trace / (rs.trace_ms * 1e-3) / 1e6 if rs.trace_ms else None,
-                    "nodes_per_ray_k_trace": float(rs.nodes_visited - rs.nodes_inline) / r_trace,
-                    "tris_per_ray_k_trace": float(rs.tris_tested - rs.tris_inline) / r_trace,
-                    "what": "this rank's share of the frame, same steps, jade_render_params.walk = JADE_WALK_REFERENCE (nodes_visited / tris_tested "
-                            "equal the oracle's); one warm-up step, then two steps + the flush inside its own clock, outside the timed region"}
+        r_trace = max(float(r_rays - rs.rays_inline - rs.rays_tail), 1.0)
+        return {"value": r_rays / rdt / 1e6, "unit": "Mray/s", "ms_per_step": rdt / k_steps * 1e3, "steps": k_steps, "warmup": args.warmup,
+                "k_trace_ms_per_step": rs.trace_ms / k_steps, "k_trace_Mray_per_s": r_trace / (rs.trace_ms * 1e-3) / 1e6 if rs.trace_ms else None,
+                "nodes_per_ray_k_trace": float(rs.nodes_visited - rs.nodes_inline - rs.nodes_tail) / r_trace,
+                "tris_per_ray_k_trace": float(rs.tris_tested - rs.tris_inline - rs.tris_tail) / r_trace,
+                "what": what}
+
+    ref_walk = early_walk = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        if walk != _abi.WALK_REFERENCE:
+            ref_walk = side_run(_abi.WALK_REFERENCE, "this rank's share of the frame, same steps and warm-up as the timed region, jade_render_params.walk = "
+                                "JADE_WALK_REFERENCE (nodes_visited / tris_tested equal the oracle's); the flush inside its clock, outside the timed region")
+        if walk == _abi.WALK_EARLY_EXIT_CACHED:
+            early_walk = side_run(_abi.WALK_EARLY_EXIT, "the same with JADE_WALK_EARLY_EXIT: early exits, no occluder cache")
 
     if rank == 0:
         # rooflines of the dominant kernel (k_trace) on THIS rank
         # k_trace traces what the fused first-pass kernel (k_light: camera rays, floor mirrors) did not trace itself
-        rays_rank = float(st.rays_primary + st.rays_secondary - st.rays_inline)
-        v_trace, t_trace = float(st.nodes_visited - st.nodes_inline), float(st.tris_tested - st.tris_inline)   # node records read / triangle tests made
+        rays_rank = float(st.rays_primary + st.rays_secondary - st.rays_inline - st.rays_tail)   # (k_tail: the render's last paths, one launch of its own)
+        v_trace, t_trace = float(st.nodes_visited - st.nodes_inline - st.nodes_tail), float(st.tris_tested - st.tris_inline - st.tris_tail)   # node records read / triangle tests made
         # bytes the REFERENCE traversal needs for k_trace's rays - with early exits the kernel reads fewer, so V and T
         # per ray come from the reference-walk steps above (the same rays: the frame is the same)
         if ref_walk is not None:
@@ -361,18 +408,24 @@ def main():
                             f"{spp_step} spp per step, tiles dealt over {world} GPU(s)",
                 "spp_per_step": spp_step, "width": width, "height": height, "triangles": hs.n_triangles,
                 "bvh_nodes": hs.n_nodes, "bvh_depth": hs.bvh_depth, "parallelism": f"tiles{world}",
-                "walk": "reference" if args.reference_walk else "early_exit",
+                "walk": walk_name,
             },
             # the same steps with every query walked to the end as the reference does (null with --reference-walk / --no-extras)
             "reference_walk": ref_walk,
-            "value_reference_walk": ref_walk["value"] if ref_walk else (None if not args.reference_walk else rays_all / dt / 1e6),
+            "value_reference_walk": ref_walk["value"] if ref_walk else (None if walk != _abi.WALK_REFERENCE else rays_all / dt / 1e6),
+            # ... and with early exits but no occluder cache (null unless the timed region ran with the cache)
+            "early_exit_walk": early_walk,
+            "value_early_exit_walk": early_walk["value"] if early_walk else (rays_all / dt / 1e6 if walk == _abi.WALK_EARLY_EXIT else None),
+            # JADE_WALK_EARLY_EXIT_CACHED: yes/no queries (shadow + environment rays) the cached subtrees answered without a walk from the root
+            "occluder_cache": {"answered": float(st.rays_cached), "share_of_shadow_and_env_rays": float(st.rays_cached) / max(float(st.rays_shadow + st.rays_env), 1.0)}
+            if walk == _abi.WALK_EARLY_EXIT_CACHED else None,
             "virtual_ranks": part_world if part_world != world else None,
             "rehearsal_all_ranks_on_one_gpu": True if rehearsal else None,
             "rays": rays_all,
             "samples": float(vals[5].item()),
             "rays_incl_warmup_this_rank": float(st.rays_primary + st.rays_secondary + st_w.rays_primary + st_w.rays_secondary),
-            "rays_k_trace_incl_warmup_this_rank": float(st.rays_primary + st.rays_secondary - st.rays_inline + st_w.rays_primary
-                                                        + st_w.rays_secondary - st_w.rays_inline),
+            "rays_k_trace_incl_warmup_this_rank": float(st.rays_primary + st.rays_secondary - st.rays_inline - st.rays_tail + st_w.rays_primary
+                                                        + st_w.rays_secondary - st_w.rays_inline - st_w.rays_tail),
             # the step by kernel on this rank: k_light (fused first pass: light samples traced and shaded in one kernel),
             # k_trace (everything else that is traced), the rest = k_shade / k_arm / gaps
             "kernels": {"k_light": {"ms_per_step": st.light_ms / max(args.steps, 1), "rays": float(st.rays_inline),
@@ -385,8 +438,10 @@ def main():
                                     "nodes_per_ray": v_trace / max(rays_rank, 1.0), "tris_per_ray": t_trace / max(rays_rank, 1.0),   # read / made by this walk
                                     "algorithmic_bytes_per_ray": alg_trace / max(rays_rank, 1.0),                                   # of the reference's walk
                                     "algorithmic_GBps": alg_trace / trace_s / 1e9 if trace_s > 0 else None},
+                        # k_tail: ONE launch that shades and traces the last paths of the render (the flush; small renders: of every step)
+                        "k_tail": {"ms": st.tail_ms, "launches": int(st.tail_launches), "rays": float(st.rays_tail)},
                         "device_ms_per_step": st.kernel_ms / max(args.steps, 1),
-                        "rest_ms_per_step": (st.kernel_ms - st.trace_ms - st.light_ms) / max(args.steps, 1)},
+                        "rest_ms_per_step": (st.kernel_ms - st.trace_ms - st.light_ms - st.tail_ms) / max(args.steps, 1)},
             "state": state,
             "rays_by_call_site": {k[5:]: float(vals[6 + i].item()) for i, k in enumerate(cls_keys)},
             "gather_ms": gather_ms,
@@ -408,6 +463,8 @@ def main():
         }
         if world == 1 and part_world == 1 and not args.no_extras and args.config in ("C2", "C3", "C4"):
             out["statue_closeup"] = closeup(scene, hip, B, H, _abi, cfg, width, height, args.spp_per_step, walk)
+        if world == 1 and part_world == 1 and not args.no_extras and args.config in ("C3", "C4"):
+            out["glass_statue"] = glass_statue(hip, J, B, _abi, width, height, args.spp_per_step, walk, check=not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(hs, cfg, width, height, args.cpu_spp)
             if parity_frame is not None:
@@ -444,6 +501,39 @@ def closeup(scene, hip, B, H, _abi, cfg, width, height, spp, walk):
             "k_trace_Mray_per_s": rays / (st.trace_ms * 1e-3) / 1e6 if st.trace_ms else None,
             "trace_share_of_step_time": st.trace_ms / st.kernel_ms if st.kernel_ms else None,
             "camera": "C3's view direction, eye moved to 0.22 from the statue's centre (C3: 0.56)"}
+
+
+def glass_statue(hip, J, B, _abi, width, height, spp, walk, check=True):
+    """Config C3G: C3's frame with the statue made of DIR_REFRACT glass (refract_mode 2, PathTrace.cu:1180-1262) - the third
+    material mode, whose serial chain of up to 32 internal reflections / refractions per sample no BASELINE config exercises
+    (rays_by_call_site.refract is 0 in every other frame of this line).  One warm-up step, one timed step, both flushed; then the
+    frame of those two steps against the oracle on three tiles (statue, floor, sky) - the checker leg, outside the clock."""
+    import numpy as np
+    from jaderaytracerendering_amd import host as H
+    hs, cfg = J.build_config("C3G")
+    spp = max(1, min(spp, 128))
+    p = B.make_params(width, height, 2 * spp, list(cfg.eye), list(cfg.camera), walk=walk)
+    with hip.scene(hs) as sc:
+        sc.begin(p)
+        w = _abi.Stats()
+        sc.step(spp, w)
+        sc.flush(w)
+        st = _abi.Stats()
+        t0 = time.perf_counter()
+        sc.step(spp, st)
+        sc.flush(st)
+        dt = time.perf_counter() - t0
+        frame = sc.resolve() if check else None
+    rays = float(st.rays_primary + st.rays_secondary)
+    out = {"value": rays / dt / 1e6, "unit": "Mray/s", "config": "C3G", "spp": spp, "rays_per_sample": rays / max(st.samples, 1),
+           "rays_by_call_site": {k[5:]: float(getattr(st, k)) for k in ("rays_primary", "rays_shadow", "rays_env", "rays_indirect", "rays_mirror", "rays_refract")},
+           "nodes_per_ray": st.nodes_visited / rays, "tris_per_ray": st.tris_tested / rays,
+           "k_trace_Mray_per_s": (rays - st.rays_inline) / (st.trace_ms * 1e-3) / 1e6 if st.trace_ms else None,
+           "trace_share_of_step_time": st.trace_ms / st.kernel_ms if st.kernel_ms else None, "k_trace_launches": int(st.trace_launches),
+           "what": "C3's geometry, camera and frame size; statue material: reflex MIRROR, refract DIR_REFRACT, index 1.5, rate (0.9, 0.95, 0.9)"}
+    if frame is not None:
+        out["parity_check"] = parity_check(hs, cfg, width, height, 2 * spp, frame, 4.0e7)
+    return out
 
 
 def parity_check(hs, cfg, width, height, spp_total, frame, ray_budget):

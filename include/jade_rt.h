@@ -34,7 +34,7 @@ extern "C" {
 
 /* bump whenever a struct layout or a documented semantic changes; callers compare
  * jade_abi_version() with the value they were compiled against */
-#define JADE_ABI_VERSION 6
+#define JADE_ABI_VERSION 7
 
 /* status codes */
 #define JADE_OK 0
@@ -164,6 +164,14 @@ typedef struct jade_render_params {
 } jade_render_params;
 #define JADE_WALK_REFERENCE 0
 #define JADE_WALK_EARLY_EXIT 1
+/* JADE_WALK_EARLY_EXIT plus an occluder cache (ABI 7).  The reference tests a leaf's triangles iff the ray meets the leaf's box
+ * and every ancestor's, and boxes are nested (jade_scene_create checks it; otherwise this mode walks as JADE_WALK_EARLY_EXIT), so
+ * a yes/no query may look ANYWHERE in the tree first: whatever triangle it finds hit below its limit there, the reference's walk
+ * finds too.  The module remembers, per (source triangle, kind of query), the subtrees in which the last such queries found their
+ * answer and walks those before the root.  The frame, the rays and the samples are the reference's bit for bit, as with
+ * JADE_WALK_EARLY_EXIT; nodes_visited / tris_tested count what was read and - the cache being shared by all waves of the device -
+ * are not the same from run to run.  jade_stats.rays_cached counts the queries the cached subtrees answered.  Oracle: ignored. */
+#define JADE_WALK_EARLY_EXIT_CACHED 2
 
 /* Exact integer work counters; the oracle's and the HIP module's must be
  * equal for the same inputs.  One "ray" is one hitBVH query
@@ -192,6 +200,15 @@ typedef struct jade_stats {
   /* HIP: the node records / triangle tests (of nodes_visited / tris_tested) that belong to the rays_inline rays, so that
    * SURVEY 8(d)'s algorithmic bytes 40 V + 36 T can be stated per kernel: k_trace's are the difference.  Oracle: 0. */
   uint64_t nodes_inline, tris_inline;
+  /* HIP, JADE_WALK_EARLY_EXIT_CACHED: shadow / environment-visibility queries (of rays_shadow + rays_env) that the occluder cache
+   * answered without a walk from the root.  Oracle and the other walks: 0. */
+  uint64_t rays_cached;
+  /* HIP (ABI 7): the last paths of a render - an active list of at most a few ten thousand records - are finished by ONE kernel,
+   * k_tail, in which every wave shades and traces its own records; its rays (of the counts above), node records, triangle tests,
+   * device time and launches.  trace_ms / trace_launches do not include them.  Oracle: 0. */
+  uint64_t rays_tail, nodes_tail, tris_tail;
+  double tail_ms;
+  uint64_t tail_launches;
 } jade_stats;
 
 typedef struct jade_scene jade_scene; /* opaque */

@@ -6,7 +6,7 @@ reference device structs, PathTrace.cu:327-351).
 """
 import ctypes as C
 
-JADE_ABI_VERSION = 6
+JADE_ABI_VERSION = 7
 JADE_SAMPLE_LANES = 1024
 JADE_OK, JADE_ERR_INVALID, JADE_ERR_DEVICE, JADE_ERR_NOMEM, JADE_ERR_UNSUPPORTED = range(5)
 DIFFUSE, MIRROR = 0, 1
@@ -14,7 +14,7 @@ NO_REFRACT, SUB_SURFACE, DIR_REFRACT = 0, 1, 2
 TILE_SIZE = 16
 TONEMAP_ACES, TONEMAP_REINHARD = 0, 1
 Q_RECORDS_PER_PIXEL, Q_STATE_BYTES, Q_SUM_LANES = 0, 1, 2
-WALK_REFERENCE, WALK_EARLY_EXIT = 0, 1
+WALK_REFERENCE, WALK_EARLY_EXIT, WALK_EARLY_EXIT_CACHED = 0, 1, 2
 
 f3 = C.c_float * 3
 f16 = C.c_float * 16
@@ -77,6 +77,9 @@ class Stats(C.Structure):
         ("rays_mirror", C.c_uint64), ("rays_refract", C.c_uint64), ("host_syncs", C.c_uint64),
         ("rays_inline", C.c_uint64), ("light_ms", C.c_double),
         ("nodes_inline", C.c_uint64), ("tris_inline", C.c_uint64),
+        ("rays_cached", C.c_uint64),
+        ("rays_tail", C.c_uint64), ("nodes_tail", C.c_uint64), ("tris_tail", C.c_uint64),
+        ("tail_ms", C.c_double), ("tail_launches", C.c_uint64),
     ]
 
     def as_dict(self):

@@ -110,6 +110,10 @@ struct DevScene {
   const uint32_t* guide;
   const uint2* guide_obj;
   uint32_t general_walk;      // an internal node lacks a child (the reference's "child 0"): every wave takes the general node step (jade_trace.h)
+  // Occluder cache (jade_trace.h): JADE_ANYHIT_KEYS entries per triangle, four internal-node references + 1 each (0 = empty); null =
+  // the tree does not allow it (boxes not nested, a missing child, too deep).  The one piece of the scene the kernels WRITE: hints
+  // only, a stale or torn entry costs a walk and never an answer.
+  uint4* anyhit;
 };
 
 // Path records, structure of arrays.  Samples are independent work items
@@ -169,7 +173,7 @@ struct PathState {
   // hit is wanted; JADE_INF_F = any recorded hit (hitArray records a hit only below INF, PathTrace.cu:787); a shadow ray carries
   // the distance at which hitTriangle meets the emitter it aims at (JADE_INF_F if it does not: then no hit can make it
   // visible).  -2 (also a NaN) = no ray in this slot.  With the reference walk k_trace ignores the word.
-  uint32_t early_exit;
+  uint32_t early_exit;  // 0: the reference's walk; 1: early exits; 2: early exits + the occluder cache (JADE_WALK_EARLY_EXIT_CACHED)
 };
 
 enum : uint32_t {
@@ -201,13 +205,15 @@ struct RenderConst {
 // (same-address device atomics retire at ~12 ns each, MI355X_MICROARCH.md
 // "fanin"); the host sums the shards after a step.
 #define JADE_CTR_SHARDS 256
-struct DevCounters {  // two 64-B lines per shard; shade_tail adds by word index, keep the order
+struct DevCounters {  // three 64-B lines per shard; shade_tail adds by word index, keep the order
   unsigned long long rays_primary, rays_shadow, nodes_visited, tris_tested, shaded_hits, samples;
   unsigned long long pad[2];  // k_trace development profile (JADE_TRACE_PROFILE)
   unsigned long long rays_env, rays_indirect, rays_mirror, rays_refract;  // with rays_shadow: rays_secondary by call site (jade_rt.h)
   unsigned long long rays_inline;  // rays k_light traced itself (primary + mirror)
   unsigned long long nodes_inline, tris_inline;  // ... and their share of nodes_visited / tris_tested
-  unsigned long long pad2[1];
+  unsigned long long rays_cached;  // yes/no queries answered by the cached subtrees alone (occluder cache, jade_trace.h)
+  unsigned long long rays_tail, nodes_tail, tris_tail;  // rays k_tail traced, and their share of nodes_visited / tris_tested
+  unsigned long long pad3[5];
 };
 #ifndef JADE_TRACE_CHUNK
 #define JADE_TRACE_CHUNK 512 /* most rays a wave claims per queue atomic */

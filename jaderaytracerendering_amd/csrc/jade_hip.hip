@@ -520,7 +520,7 @@ __global__ void k_ray_keys(PathState P, const uint32_t* queue, uint32_t n, uint3
   keys[i] = (cls << 29) | (((tri << 3) | oct) << (26u - tri_bits));  // left-aligned: kind, triangle, octant
 }
 
-#define JADE_CTL_RING 32 /* QueueCtl records: entry 0 for passes the host follows one by one, all of them for a batch of passes */
+#define JADE_CTL_RING 96 /* QueueCtl records: entry 0 for passes the host follows one by one, all of them for a batch of passes (round 4: 96 - a 1024-spp step of C3 is ~65 passes down to its carry-over point, the flush ~65 more down to k_tail's threshold: one batch, one wait each; the launches behind the stop are empty) */
 #ifndef JADE_TRACE_NT
 #define JADE_TRACE_NT 1 /* k_trace reads and writes the ray records with non-temporal hints */
 #endif
@@ -546,11 +546,34 @@ static __device__ __forceinline__ void nt_st4(float4* p, float x, float y, float
 #ifndef JADE_TRACE_WAVES
 #define JADE_TRACE_WAVES 5 /* waves per SIMD the register allocation leaves room for: 5 = at most 96 VGPRs (12 bytes of scratch) and 5 x 31 KB of LDS per CU.  Round 3, same process, C3 / statue close-up: 4 waves (102 VGPRs) 133.6 / 1037 ms of k_trace per 256-spp step, 5 waves 126.9 / 983 (round 2's "5 and 6 blocks per CU are no faster" was measured on a 102-VGPR build, which the hardware never ran at more than 4) */
 #endif
+// occluder cache (jade_trace.h): the key of a yes/no query - k: its slot in the record (shadow ray towards emitter k, then the
+// environment-visibility ray), d: its direction
+static __device__ __forceinline__ uint32_t anyhit_key(uint32_t k, uint32_t n_emit, jvec3 d) {
+  const uint32_t oct = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+  return k < n_emit ? (k != 0u ? 1u : 0u) : 2u + oct;
+}
+typedef uint32_t jade_v4u __attribute__((ext_vector_type(4)));
+static __device__ __forceinline__ uint4 ld_anyhit(const uint4* p) {
+  const jade_v4u v = NT_LD(reinterpret_cast<const jade_v4u*>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
 // WIDE: the walk may take wide units (jade_trace.h, "Wide walk"): k_trace_wide, launched instead of k_trace for renders with
 // early exits on trees that have wide records.
-template <bool WIDE>
+// TAIL (k_tail): the kernel also SHADES - every wave owns 64 records of a short list and alternates, on its own, k_shade's pass over
+// them (shade_record, the rays emitted into a stretch of the queue that is the wave's own) and this loop over those rays, until its
+// records have run out of samples.  No other wave is waited for: what a render's last paths cost is their own chain of bounces,
+// not one launch (and, at the end of a batch, one host wait) per bounce.
+struct TailArgs {
+  RenderConst R;
+  const int32_t* tile_ids;
+  uint32_t target_spp;
+  const uint32_t* list;  // the records (the active list)
+  uint32_t n_list;
+  uint32_t* queue;       // a wave's stretch: 64 * nslots entries
+};
+template <bool WIDE, bool TAIL = false>
 static __device__ __forceinline__ void trace_body(const DevScene& S, const PathState& P, const uint32_t* queue, QueueCtl* qc, uint32_t* spill, DevCounters* ctr,
-                                                  uint32_t chunk) {
+                                                  uint32_t chunk, const TailArgs* tail = nullptr) {
   __shared__ uint32_t lds_cols[TW_END * JADE_TRACE_BLOCK];
   __shared__ __attribute__((aligned(8))) uint32_t lds_wq[JADE_TRACE_BLOCK / 64][2 * JADE_WQ];  // a wave's ring of leaves to test (jade_trace.h)
   __shared__ __attribute__((aligned(8))) uint32_t lds_hq[JADE_TRACE_BLOCK / 64][2 * JADE_HQ];  // and its ring of hit candidates  // a wave's queue of leaves to test (jade_trace.h)
@@ -565,12 +588,12 @@ static __device__ __forceinline__ void trace_body(const DevScene& S, const PathS
   stk.top_k = 0;
   stk.top4 = nullptr;
   stk.top4_k = 0;
-  if (qc->count == 0) return;  // (a pass of a batch behind the one that ended the step: nothing was queued)
+  if (!TAIL && qc->count == 0) return;  // (a pass of a batch behind the one that ended the step: nothing was queued)
   // The grid is sized for a full queue (in a batch of passes the host does not know the length); a short queue keeps one
   // block per JADE_TRACE_BLOCK rays and the others leave before they stage anything: the thin passes at the end of a render
   // (under 10 k rays: 40 blocks instead of 1280) were mostly 1280 copies of the tree top into LDS.  The blocks that stay claim
   // chunks until the queue is empty, as ever.
-  if ((unsigned long long)blockIdx.x * JADE_TRACE_BLOCK >= (unsigned long long)qc->count) return;
+  if (!TAIL && (unsigned long long)blockIdx.x * JADE_TRACE_BLOCK >= (unsigned long long)qc->count) return;
 #if JADE_TRACE_TOP_NODES > 0 && JADE_LDS_TOP_NODES > 0
   static_assert(7 * JADE_TRACE_TOP4 <= 4 * JADE_TRACE_TOP_NODES, "the wide top shares the binary top's LDS");
   __shared__ float4 lds_top[4 * JADE_TRACE_TOP_NODES];
@@ -593,8 +616,8 @@ static __device__ __forceinline__ void trace_body(const DevScene& S, const PathS
     stk.top_k = k;
   }
 #endif
-  const uint32_t n = qc->count;
-  if (chunk == 0) {  // batched passes: the host has not seen the queue length (trace_chunk's rule, on the device)
+  uint32_t n = TAIL ? 0u : qc->count;
+  if (!TAIL && chunk == 0) {  // batched passes: the host has not seen the queue length (trace_chunk's rule, on the device)
     const uint32_t waves = gridDim.x * (JADE_TRACE_BLOCK / 64);
     uint32_t per = n / (waves * 64u * 8u);
     per = per < 1u ? 1u : (per > JADE_TRACE_CHUNK / 64 ? JADE_TRACE_CHUNK / 64 : per);
@@ -602,6 +625,8 @@ static __device__ __forceinline__ void trace_body(const DevScene& S, const PathS
   }
   uint32_t V = 0, T = 0;  // wave totals (uniform: they live in SGPRs)
   uint32_t vcnt = 0, tcnt = 0;  // per lane, summed over the wave once at the end (a ballot + popcount per unit was 8 instructions)
+  uint32_t ccnt = 0;            // ... queries answered by the occluder cache
+  const bool anyhit = P.early_exit == 2u && S.anyhit != nullptr;  // (uniform)
   // wave-local chunk of the queue: [lbase, lend) (wave-uniform)
   uint32_t lbase = 0, lend = 0;
   bool queue_empty = false;
@@ -630,20 +655,68 @@ static __device__ __forceinline__ void trace_body(const DevScene& S, const PathS
   __shared__ __attribute__((aligned(8))) unsigned long long lds_prof[JADE_TRACE_BLOCK / 64][PL_N];
   pr.begin(lds_addr_of(reinterpret_cast<const uint32_t*>(&lds_prof[threadIdx.x >> 6][0])), lane);
 #endif
+  // ---- TAIL: this wave's records, and the totals of what shading them counts (shade_tail's counters, per wave here)
+  int tail_p = P.npix;     // this lane's record (npix = none)
+  bool tail_alive = false;
+  unsigned long long tail_rays = 0;  // rays this wave traced (uniform)
+  unsigned long long tc_primary = 0, tc_shadow = 0, tc_shaded = 0, tc_samples = 0, tc_env = 0, tc_ind = 0, tc_mirror = 0, tc_refract = 0;  // (valid in lane 0)
+  if (TAIL) {
+    const uint32_t wave_id = blockIdx.x * (JADE_TRACE_BLOCK / 64) + (threadIdx.x >> 6);
+    const uint32_t t_idx = wave_id * 64u + (uint32_t)lane;
+    if (t_idx < tail->n_list) {
+      tail_p = (int)tail->list[t_idx];
+      tail_alive = true;
+    }
+    queue = tail->queue + (size_t)wave_id * 64u * (uint32_t)P.nslots;
+  }
+  for (;;) {  // (TAIL: one turn per bounce of the wave's records; otherwise one turn)
+  if (TAIL) {
+    // ---- k_shade's pass over the wave's records: last turn's hit results folded in, the next bounce's rays emitted
+    __threadfence();  // the results this wave's lanes wrote for each other's records
+    ShadeCtx c;
+    c.n_emit_rays = 0;
+    c.c_primary = c.c_shadow = c.c_shaded = c.c_samples = c.c_cls = 0;
+    uint32_t st = ST_INVALID;
+    if (tail_alive) {
+      bool defer;
+      shade_record<false>(S, P, tail->R, tail->tile_ids, tail->target_spp, tail_p, c, st, defer);
+      tail_alive = c.n_emit_rays > 0;  // a record without a ray in flight has run out of samples
+    }
+    tc_primary += wave_sum_u32(c.c_primary); tc_shadow += wave_sum_u32(c.c_shadow); tc_shaded += wave_sum_u32(c.c_shaded); tc_samples += wave_sum_u32(c.c_samples);
+    tc_env += wave_sum_u32(c.c_cls & 255u); tc_ind += wave_sum_u32((c.c_cls >> 8) & 255u); tc_mirror += wave_sum_u32((c.c_cls >> 16) & 255u); tc_refract += wave_sum_u32(c.c_cls >> 24);
+    if (__ballot(tail_alive) == 0ull) break;
+    // the wave's rays, slot by slot as shade_tail queues them
+    uint32_t m_rays = 0;
+    const int used = !tail_alive ? 0 : (st == ST_DIFFUSE || st == ST_BSSRDF) ? P.nslots : 1;
+    for (int k = 0; k < P.nslots; ++k) {
+      const bool q = k < used && reinterpret_cast<const int*>(P.slot + ((size_t)tail_p * P.nslots + k) * 2)[3] != -2;
+      const unsigned long long m = __ballot(q);
+      if (q) const_cast<uint32_t*>(queue)[m_rays + wt.rank_in(m)] = (uint32_t)tail_p * (uint32_t)P.nslots + (uint32_t)k;
+      m_rays += (uint32_t)__popcll(m);
+    }
+    __threadfence();  // rays and queue entries are read by other lanes of this wave
+    n = m_rays;
+    tail_rays += m_rays;
+    lbase = 0;
+    lend = n;
+    queue_empty = false;
+  }
   for (;;) {
     // ---- a ray has ended when its walk has and all the leaves it pushed have been finished
     if (active && WaveTrace::ray_ended(r, stk)) {
+      // (occluder cache: the cached subtrees held no answer - the whole walk, from the root)
+      const bool retry = (r.skipx & (JADE_ATTEMPT | JADE_CUT)) == JADE_ATTEMPT;
       // (wide walk: two leaves tied for this ray's best distance and the walk was not the reference's order - once more, with
       // binary units only; a ray that ended early has its answer whatever the order)
       const bool again = WIDE && lds_get(stk, TW_LIMIT) == JADE_LIMIT_TIE && (r.skipx & (JADE_CUT | JADE_FORCE_BINARY)) == 0u;
-      if (again) {
-        const uint32_t p = my_e / (uint32_t)P.nslots;
-        const float4 og = nt_ld4(&P.orgs[p]);
-        const int32_t skip = __float_as_int(og.w);
-        const jvec3 o = skip == JADE_SKIP_CAMERA ? jv(P.eye[0], P.eye[1], P.eye[2]) : jv(og.x, og.y, og.z);
-        const float4 dv = nt_ld4(&P.slot[(size_t)my_e * 2]);
-        walk_begin(r, stk, S, o, jv(dv.x, dv.y, dv.z), skip, P.early_exit ? dv.w : __int_as_float(-1));
-        r.skipx |= JADE_FORCE_BINARY;
+      if (retry || again) {
+        // the ray is still in the lane's registers (origin, directions, source triangle, the limit in its column): only the walk
+        // starts over - from the root, with nothing found (a hit of the first walk is found again; keeping it would mix the two
+        // walks' leaf numbers in hitArray's tie rule).  No memory access: this runs whenever ANY lane of the wave restarts.
+        walk_restart(r, stk, S);
+        r.skipx = (r.skipx & ~JADE_ATTEMPT) | (retry ? 0u : JADE_FORCE_BINARY);
+        if (WIDE && lds_get(stk, TW_LIMIT) == JADE_LIMIT_TIE)  // (rare: the tie marker sits where the limit was - the ray's own comes back from its slot)
+          lds_putf(stk, TW_LIMIT, P.early_exit ? NT_LD(reinterpret_cast<const float*>(P.slot + (size_t)my_e * 2) + 3) : __int_as_float(-1));
       } else {
         active = false;
         wb = true;
@@ -663,16 +736,33 @@ static __device__ __forceinline__ void trace_body(const DevScene& S, const PathS
         // 4 MB L2 (C3's node + vertex records are 4.1 MB; PMC: 124 of the 172 HBM bytes per ray were BVH lines re-fetched)
         float dist;
         jvec3 hp = jv(0, 0, 0);
-        const int32_t best = walk_result(stk, S, r.od, &dist, &hp);
+        uint32_t parent1 = 0;
+        const int32_t best = walk_result(stk, S, r.od, &dist, &hp, &parent1);
         float4* sl = P.slot + (size_t)my_e * 2;
         NT_ST(reinterpret_cast<int32_t*>(sl) + 3, best);
         nt_st4(sl + 1, hp.x, hp.y, hp.z, dist);  // (the hit point of a miss is never read; its distance stays INF, PathTrace.cu:799)
+        if (anyhit) {
+          // occluder cache: an answer the cached subtrees gave is counted; one that took the whole walk leaves its leaf's parent
+          // in one of the key's four ways (a plain store: entries are hints)
+          ccnt += (r.skipx & (JADE_CUT | JADE_ATTEMPT)) == (JADE_CUT | JADE_ATTEMPT) ? 1u : 0u;
+          const uint32_t src = r.skipx & JADE_SKIP_MASK;
+          const float lim = lds_getf(stk, TW_LIMIT);
+          if ((r.skipx & (JADE_CUT | JADE_ATTEMPT | 0x80000000u)) == JADE_CUT && parent1 != 0u && lim == lim && src != JADE_SKIP_MASK) {
+            const uint32_t k = my_e - (my_e / (uint32_t)P.nslots) * (uint32_t)P.nslots;
+            const jvec3 dn = od_dn(r.od);
+            const uint32_t key = anyhit_key(k, (uint32_t)S.n_emit, dn);
+            const uint32_t way = (my_e * 2654435761u) >> 30;
+            reinterpret_cast<uint32_t*>(S.anyhit)[((size_t)src * JADE_ANYHIT_KEYS + key) * 4u + way] = parent1;
+          }
+        }
         wb = false;
       }
       PROF_DRAIN();
       PROF_LAP(pr, PL_WRITEBACK);
       if (!queue_empty) {
-        if (lbase >= lend) {
+        if (TAIL && lbase >= lend) queue_empty = true;  // (the wave's own stretch: nothing to claim.  Found here, with nothing taken -
+        // not when the last entries are taken: the lanes that took them are counted idle by this turn of the loop)
+        if (!TAIL && lbase >= lend) {
           uint32_t nb = 0;
           if (lane == 0) nb = atomicAdd(&qc->next, chunk);
           nb = __shfl(nb, 0, 64);
@@ -695,7 +785,29 @@ static __device__ __forceinline__ void trace_body(const DevScene& S, const PathS
           const jvec3 o = skip == JADE_SKIP_CAMERA ? jv(P.eye[0], P.eye[1], P.eye[2]) : jv(og.x, og.y, og.z);
           const float4 dv = nt_ld4(&P.slot[(size_t)my_e * 2]);
           const jvec3 d = jv(dv.x, dv.y, dv.z);
+          // occluder cache (jade_trace.h): a yes/no query starts with the subtrees in which the last such queries from this
+          // triangle found their answer - the lane's stack begins with them instead of the root.  (The entry is requested before
+          // walk_begin's arithmetic so that the two overlap.)
+          const bool anyq = anyhit && dv.w == dv.w && skip >= 0;
+          uint4 c = make_uint4(0u, 0u, 0u, 0u);
+          if (anyq) c = ld_anyhit(S.anyhit + (size_t)skip * JADE_ANYHIT_KEYS + anyhit_key(my_e - p * (uint32_t)P.nslots, (uint32_t)S.n_emit, d));
           walk_begin(r, stk, S, o, d, skip, P.early_exit ? dv.w : __int_as_float(-1));
+          if (anyq && (int32_t)r.skipx >= 0) {  // (a ray with a non-finite 1/d takes the NaN-faithful walk from the root)
+            uint32_t cur = JADE_REF_NONE, sp = stk.col;
+            const uint32_t e4[4] = {c.w, c.z, c.y, c.x};  // way 0 is walked first: the others go under it
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const bool have = e4[i] != 0u, push = have && cur != JADE_REF_NONE;
+              lds_st(push ? sp : stk.col + TW_DUMMY * JADE_COL_STRIDE, cur);
+              sp += push ? JADE_COL_STRIDE : 0u;
+              cur = have ? e4[i] - 1u : cur;
+            }
+            if (cur != JADE_REF_NONE) {
+              r.cur = cur;
+              r.sp = sp;
+              r.skipx |= JADE_ATTEMPT;
+            }
+          }
           active = true;
         }
         V += take;  // the root record of every ray started
@@ -707,6 +819,19 @@ static __device__ __forceinline__ void trace_body(const DevScene& S, const PathS
     if (n_idle == 64 && queue_empty) break;  // nothing in flight (so no leaf is waiting either), nothing left to claim
     // ---- one iteration of work for the wave: walk units, test units or a pass over the hit candidates (jade_trace.h)
     wt.template iterate<WIDE>(r, active, S, stk, vcnt, tcnt, pr);
+  }
+  if (!TAIL) break;
+  }
+  if (TAIL && lane == 0) {  // what shading counted (shade_tail's words of DevCounters)
+    DevCounters* cs = ctr + (blockIdx.x % JADE_CTR_SHARDS);
+    if (tc_primary) atomicAdd(&cs->rays_primary, tc_primary);
+    if (tc_shadow) atomicAdd(&cs->rays_shadow, tc_shadow);
+    if (tc_shaded) atomicAdd(&cs->shaded_hits, tc_shaded);
+    if (tc_samples) atomicAdd(&cs->samples, tc_samples);
+    if (tc_env) atomicAdd(&cs->rays_env, tc_env);
+    if (tc_ind) atomicAdd(&cs->rays_indirect, tc_ind);
+    if (tc_mirror) atomicAdd(&cs->rays_mirror, tc_mirror);
+    if (tc_refract) atomicAdd(&cs->rays_refract, tc_refract);
   }
 #if JADE_TRACE_PROFILE
   pr.count(PC_WAVES, 1);
@@ -722,6 +847,15 @@ static __device__ __forceinline__ void trace_body(const DevScene& S, const PathS
     DevCounters* cs = ctr + (blockIdx.x % JADE_CTR_SHARDS);
     if (V) atomicAdd(&cs->nodes_visited, (unsigned long long)V);
     if (T) atomicAdd(&cs->tris_tested, (unsigned long long)T);
+    if (TAIL) {  // k_tail's own share (jade_stats.rays_tail ...): its rays are not k_trace's
+      if (tail_rays) atomicAdd(&cs->rays_tail, tail_rays);
+      if (V) atomicAdd(&cs->nodes_tail, (unsigned long long)V);
+      if (T) atomicAdd(&cs->tris_tail, (unsigned long long)T);
+    }
+  }
+  if (anyhit) {
+    const uint32_t C = (uint32_t)wave_sum_u32(ccnt);
+    if (lane == 0 && C) atomicAdd(&(ctr + (blockIdx.x % JADE_CTR_SHARDS))->rays_cached, (unsigned long long)C);
   }
 }
 __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(DevScene S, PathState P, const uint32_t* queue, QueueCtl* qc,
@@ -734,6 +868,17 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WAVES) void k_trace(De
 __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TRACE_WIDE_WAVES) void k_trace_wide(DevScene S, PathState P, const uint32_t* queue, QueueCtl* qc,
                                                                 uint32_t* spill, DevCounters* ctr, uint32_t chunk) {
   trace_body<true>(S, P, queue, qc, spill, ctr, chunk);
+}
+#ifndef JADE_TAIL_WAVES
+#define JADE_TAIL_WAVES 2 /* k_tail holds k_shade's registers and k_trace's at once (152 VGPRs; at 4 waves per SIMD it spills 372 bytes); at most a few hundred waves ever run, so occupancy is not what it needs */
+#endif
+#ifndef JADE_TAIL_MAX
+#define JADE_TAIL_MAX 32768u /* records: a shorter active list is finished by k_tail instead of by further passes */
+#endif
+// k_tail: the end of a render's (or a small render's) paths in ONE launch - see TailArgs.  Binary units only: the walk is the
+// reference's in every mode, and early exits work as in k_trace (the limit travels in the slot).
+__global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_TAIL_WAVES) void k_tail(DevScene S, PathState P, TailArgs tail, uint32_t* spill, DevCounters* ctr) {
+  trace_body<false, true>(S, P, nullptr, nullptr, spill, ctr, 64u, &tail);
 }
 // which of the two a launch takes: wide units need early exits (the order of the walk is then nobody's business but a tie's) and
 // a tree with wide records
@@ -1443,8 +1588,14 @@ struct Tunables {
   int packet_budget = JADE_PACKET_BUDGET;  // JADE_PACKET_BUDGET: records a packet may read before it is given up and walked per lane
   int wide_mode = -1;         // JADE_WIDE: with early exits k_trace walks four grandchildren per visit (k_trace_wide): 1 always, 0 never, unset =
                               // when the traversal's records do not fit the L2 (the rule of sort_mode; jade_scene_create then builds wide records)
+  bool tail = true;           // JADE_TAIL=0: no k_tail - the last paths are finished by passes, as before round 4
+  uint32_t tail_max = JADE_TAIL_MAX;  // JADE_TAIL_MAX: active records at or below which k_tail takes over
+  bool anyhit = true;         // JADE_ANYHIT=0: no occluder cache (JADE_WALK_EARLY_EXIT_CACHED then walks as JADE_WALK_EARLY_EXIT)
   void read() {
     auto flag0 = [](const char* n) { const char* e = getenv(n); return e && atoi(e) == 0; };
+    anyhit = !flag0("JADE_ANYHIT");
+    tail = !flag0("JADE_TAIL");
+    if (const char* e = getenv("JADE_TAIL_MAX")) tail_max = (uint32_t)atoi(e);
     auto flag1 = [](const char* n) { const char* e = getenv(n); return e && atoi(e) > 0; };
     shade_split = !flag0("JADE_SHADE_SPLIT");
     fused = shade_split && !flag0("JADE_FUSED");
@@ -1469,7 +1620,8 @@ struct jade_scene {
   Tunables tun;
   hipStream_t stream = nullptr;
   DevScene dev{};
-  DevBuf b_nodes, b_nodes4, b_tverts, b_tris, b_emit, b_mapping, b_prefix, b_segs, b_env, b_guide, b_guide_obj, b_tnorm, b_mats;
+  DevBuf b_nodes, b_nodes4, b_tverts, b_tris, b_emit, b_mapping, b_prefix, b_segs, b_env, b_guide, b_guide_obj, b_tnorm, b_mats, b_anyhit;
+  bool boxes_nested = true;   // every child's box lies inside its parent's (jade_scene_create): what the wide walk and the occluder cache need
   int n_emit = 0;
   int bvh_depth = 0;
   bool sort_rays = false;     // the ray queue is ordered before every k_trace launch (Tunables.sort_mode; then passes are host-followed)
@@ -1490,15 +1642,21 @@ struct jade_scene {
   double packets_given_up = 0;  // share of the last fused pass's packets that were given up (reset by jade_render_begin)
   int64_t spp_done = 0;
   bool tail_pending = false;  // the last step left its longest paths unfinished (jade_render_flush)
+  uint32_t carried_active = 0;  // ... this many records (0: unknown)
   hipEvent_t ev[7] = {};      // run_passes' timing events, made once (ev0, ev1, ta, tb, sa, sb, sm)
   hipEvent_t ev_resolve = nullptr;  // jade_render_resolve_tiles_device: caller's stream -> scene stream
   uint64_t host_syncs = 0;    // host waits inside step/flush since the last advance() reported them
   double light_ms = 0;        // k_light device time since then
   hipEvent_t ev_light[2] = {};
+  hipEvent_t ev_tail[2] = {};
+  double tail_ms = 0;         // k_tail device time since the last advance() reported it
+  uint64_t tail_launches = 0, tail_records = 0;
   hipEvent_t ev_batch[2 * JADE_CTL_RING] = {};  // k_trace timing of a batch of passes
   ~jade_scene() {
     if (ev_resolve) (void)hipEventDestroy(ev_resolve);
     for (hipEvent_t e : ev_light)
+      if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ev_tail)
       if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_batch)
       if (e) (void)hipEventDestroy(e);
@@ -1601,8 +1759,19 @@ static int rccl_gather(jade_scene* const* scenes, int ndev, float* dst, const st
     const ncclResult_t r2 = g_rccl.GroupEnd();
     if (r == ncclSuccess) r = r2;
   }
-  if (dev_err) return fail(JADE_ERR_DEVICE, dev_err);
-  if (r != ncclSuccess) return fail(JADE_ERR_DEVICE, std::string("RCCL gather: ") + g_rccl.GetErrorString(r));
+  if (dev_err || r != ncclSuccess) {
+    // a communicator that saw a failed send / receive / group may be in an error state: it is destroyed and forgotten, the next
+    // gather over these devices bootstraps fresh ones
+    for (size_t k = 0; k < g_comm_sets.size(); ++k)
+      if (&g_comm_sets[k] == cs) {
+        for (ncclComm_t c : g_comm_sets[k].comms)
+          if (c) (void)g_rccl.CommDestroy(c);
+        g_comm_sets.erase(g_comm_sets.begin() + (long)k);
+        break;
+      }
+    if (dev_err) return fail(JADE_ERR_DEVICE, dev_err);
+    return fail(JADE_ERR_DEVICE, std::string("RCCL gather: ") + g_rccl.GetErrorString(r));
+  }
   // rank 0's own share does not travel; then every stream involved drains before the caller reads the buffer
   hipError_t e = hipSetDevice(scenes[0]->device);
   const size_t own = (size_t)scenes[0]->ps.npx * 12;
@@ -1778,7 +1947,26 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
   tun0.read();
   const size_t geometry_bytes0 = ((size_t)4 * std::max(n_internal, 1) + (size_t)5 * std::max<size_t>(n_pairs, 1)) * sizeof(float4);
   const bool want_wide = tun0.wide_mode < 0 ? geometry_bytes0 > JADE_SORT_GEOMETRY_BYTES : tun0.wide_mode > 0;
-  if (JADE_WIDE_WALK && want_wide && !missing_child && n_internal > 0) {
+  // The wide walk and the occluder cache both rest on "a ray that meets a node's box meets every ancestor's" (jade_trace.h), which
+  // holds when every child's box lies inside its parent's, bound by bound, with no NaN - true of any tree built by min / max over
+  // the triangles (this repo's builders, the reference's), but the caller's array is the caller's: a tree with padded,
+  // refitted or NaN boxes is walked with binary units from the root only, which needs no such property.
+  bool nested = true;
+  for (int i = 1; i < nN && nested; ++i) {
+    const jade_bvh_node& nd = d->nodes[i];
+    if (nd.n > 0) continue;
+    for (int ch : {nd.left, nd.right}) {
+      if (ch <= 0) continue;
+      const jade_bvh_node& c = d->nodes[ch];
+      for (int a = 0; a < 3; ++a)
+        if (!(c.aa[a] >= nd.aa[a] && c.bb[a] <= nd.bb[a] && c.aa[a] <= c.bb[a])) nested = false;  // (a NaN fails every comparison)
+    }
+  }
+  // stack levels a walk may need (validate_desc bounds the binary walk's: depth <= capacity - 1): a wide unit pushes up to three
+  // entries for every two levels it descends; a walk that starts with the cached subtrees has three more under it
+  const bool wide_fits = 3 * ((depth + 1) / 2) + 1 + 3 <= JADE_BVH_STACK_CAPACITY;
+  const bool cache_fits = depth + 3 <= JADE_BVH_STACK_CAPACITY - 1;
+  if (JADE_WIDE_WALK && want_wide && !missing_child && n_internal > 0 && nested && wide_fits) {
     nodes4.assign((size_t)8 * n_internal, make_float4(0, 0, 0, 0));
     for (int i = 1; i < nN; ++i) {
       const jade_bvh_node& nd = d->nodes[i];
@@ -1807,6 +1995,13 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
     }
   }
   std::vector<float4> tverts((size_t)5 * std::max<size_t>(n_pairs, 1));
+  std::vector<int32_t> leaf_parent(nN, 0);
+  for (int i = 1; i < nN; ++i) {
+    const jade_bvh_node& nd = d->nodes[i];
+    if (nd.n > 0) continue;
+    if (nd.left > 0 && d->nodes[nd.left].n > 0) leaf_parent[nd.left] = i;
+    if (nd.right > 0 && d->nodes[nd.right].n > 0) leaf_parent[nd.right] = i;
+  }
   for (int i = 1; i < nN; ++i) {
     const jade_bvh_node& nd = d->nodes[i];
     for (int k = 0; k < nd.n; k += 2) {
@@ -1818,7 +2013,11 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
       o[1] = make_float4(a.p1[2], b.p1[2], a.p2[0], b.p2[0]);
       o[2] = make_float4(a.p2[1], b.p2[1], a.p2[2], b.p2[2]);
       o[3] = make_float4(a.p3[0], b.p3[0], a.p3[1], b.p3[1]);
-      const uint32_t tag[2] = {(uint32_t)(nd.index + k), has_b ? 1u : 0u};
+      // flag word: bit 0 = B is a triangle; bits 1-31 = the leaf's parent + 1 (occluder cache, jade_trace.h; 0 = the root or none: a
+      // walk "from the root" is the whole walk, nothing to cache)
+      const int par = leaf_parent[i];
+      const uint32_t parent1 = (par > 1 && compact[par] > 0) ? (uint32_t)compact[par] + 1u : 0u;
+      const uint32_t tag[2] = {(uint32_t)(nd.index + k), (has_b ? 1u : 0u) | (parent1 << 1)};
       float tagf[2];
       memcpy(tagf, tag, 8);
       o[4] = make_float4(a.p3[2], b.p3[2], tagf[0], tagf[1]);
@@ -1921,7 +2120,12 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
   if (e == hipSuccess) e = upload(s->b_mats, mats.data(), mats.size(), s->stream);
   if (e == hipSuccess) e = upload(s->b_guide, guide.data(), guide.size(), s->stream);
   if (e == hipSuccess) e = upload(s->b_guide_obj, guide_obj.data(), guide_obj.size(), s->stream);
-  if (e == hipSuccess) e = s->b_ctl.alloc(sizeof(QueueCtl) * JADE_CTL_RING);
+  const bool want_anyhit = s->tun.anyhit && nested && cache_fits && !missing_child && n_internal > 1;
+  if (e == hipSuccess && want_anyhit) {
+    e = s->b_anyhit.alloc((size_t)d->n_triangles * JADE_ANYHIT_KEYS * sizeof(uint4));
+    if (e == hipSuccess) e = hipMemsetAsync(s->b_anyhit.p, 0, s->b_anyhit.bytes, s->stream);
+  }
+  if (e == hipSuccess) e = s->b_ctl.alloc(sizeof(QueueCtl) * (JADE_CTL_RING + 1));  // (+ 1: k_arm's count when the host does not wait for it)
   if (e == hipSuccess) e = s->b_ctr.alloc(sizeof(DevCounters) * JADE_CTR_SHARDS);
   if (e != hipSuccess) {
     delete s;
@@ -1947,6 +2151,8 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
   s->dev.root_ref = ref_of(1);
   s->dev.top_k = (uint32_t)std::min(n_internal, (int)JADE_LDS_TOP_NODES);
   s->dev.general_walk = missing_child ? 1u : 0u;
+  s->dev.anyhit = want_anyhit ? s->b_anyhit.as<uint4>() : nullptr;
+  s->boxes_nested = nested;
   // Ray ordering pays when the traversal's records do not fit the XCDs' L2s (C5: 55 MB, k_trace bound by the rate of 64-B sector
   // misses: 4 235 -> 5 275 Mray/s); on a tree that does (C3: 3.8 MB) it costs more than it gives
   {
@@ -2064,7 +2270,8 @@ int jade_render_begin(jade_scene* s, const jade_render_params* rp) {
   if (!s || !rp) return fail(JADE_ERR_INVALID, "null argument");
   if (rp->width <= 0 || rp->height <= 0 || rp->tile_nranks <= 0 || rp->tile_rank < 0 || rp->tile_rank >= rp->tile_nranks)
     return fail(JADE_ERR_INVALID, "bad image size or tile partition");
-  if (rp->walk != JADE_WALK_REFERENCE && rp->walk != JADE_WALK_EARLY_EXIT) return fail(JADE_ERR_INVALID, "unknown walk (JADE_WALK_*)");
+  if (rp->walk != JADE_WALK_REFERENCE && rp->walk != JADE_WALK_EARLY_EXIT && rp->walk != JADE_WALK_EARLY_EXIT_CACHED)
+    return fail(JADE_ERR_INVALID, "unknown walk (JADE_WALK_*)");
   HIP_TRY(hipSetDevice(s->device));
   const int tx = (rp->width + JADE_TILE_SIZE - 1) / JADE_TILE_SIZE, ty = (rp->height + JADE_TILE_SIZE - 1) / JADE_TILE_SIZE;
   s->tile_ids.clear();
@@ -2123,11 +2330,12 @@ int jade_render_begin(jade_scene* s, const jade_render_params* rp) {
   R.aspect = (double)rp->width / (double)rp->height;
   s->spp_done = 0;
   s->tail_pending = false;
+  s->carried_active = 0;
   s->packets_given_up = 0;
   if (npix64 == 0) { s->ps.npix = 0; s->ps.npx = 0; s->have_rp = true; return JADE_OK; }
   int rc = setup_state(s, (int)npx64, rpp, nslots, sum_lanes);
   if (rc) return rc;
-  s->ps.early_exit = rp->walk == JADE_WALK_EARLY_EXIT ? 1u : 0u;
+  s->ps.early_exit = rp->walk == JADE_WALK_EARLY_EXIT_CACHED ? 2u : rp->walk == JADE_WALK_EARLY_EXIT ? 1u : 0u;
   memcpy(s->ps.eye, rp->eye, sizeof s->ps.eye);
   HIP_TRY(upload(s->b_tiles, s->tile_ids.data(), s->tile_ids.size(), s->stream));
   HIP_TRY(hipMemsetAsync(s->b_ctr.p, 0, sizeof(DevCounters) * JADE_CTR_SHARDS, s->stream));
@@ -2161,6 +2369,8 @@ static hipError_t sum_counters(jade_scene* s, DevCounters* out) {
     out->rays_mirror += c.rays_mirror; out->rays_refract += c.rays_refract;
     out->rays_inline += c.rays_inline;
     out->nodes_inline += c.nodes_inline; out->tris_inline += c.tris_inline;
+    out->rays_cached += c.rays_cached;
+    out->rays_tail += c.rays_tail; out->nodes_tail += c.nodes_tail; out->tris_tail += c.tris_tail;
     out->pad[0] += c.pad[0]; out->pad[1] += c.pad[1];
   }
   return e;
@@ -2189,8 +2399,18 @@ static int run_passes(jade_scene* s, int64_t from_spp, uint32_t target_spp, bool
   // records itself); otherwise - a flush, a step of fewer samples than records per pixel - k_arm lists and counts them
   uint32_t host_ctl[3] = {0, 0, 0};
   uint32_t n_active;
+  const uint32_t* arm_dev = nullptr;  // k_arm's count, on the device, when the host has not waited for it
   if (fused && s->ps.stride == 0 && (int64_t)target_spp - from_spp >= (int64_t)s->ps.rpp) {
     n_active = (uint32_t)npix;
+  } else if ((int64_t)target_spp == from_spp && s->carried_active > 0 && s->tun.batching && !s->sort_rays && !s->tun.log_passes && s->ps.stride == 0) {
+    // A flush: no sample is started, so the records with work are exactly the ones the last step carried over, and the host knows
+    // how many those were - k_arm lists them, the first pass of the batch below reads the count on the device, nobody waits.
+    QueueCtl* qa = qc + JADE_CTL_RING;
+    HIP_TRY(hipMemsetAsync(qa, 0, 12, s->stream));
+    hipLaunchKernelGGL(k_arm, dim3((unsigned)(((size_t)npix + JADE_ARM_BLOCK * JADE_ARM_PER_THREAD - 1) / (JADE_ARM_BLOCK * JADE_ARM_PER_THREAD))), dim3(JADE_ARM_BLOCK), 0, s->stream, s->ps, target_spp,
+                       s->b_active[0].as<uint32_t>(), qa);
+    n_active = s->carried_active;  // (an upper bound is all the grids need)
+    arm_dev = &qa->active;
   } else {
     HIP_TRY(hipMemsetAsync(qc, 0, 12, s->stream));
     hipLaunchKernelGGL(k_arm, dim3((unsigned)(((size_t)npix + JADE_ARM_BLOCK * JADE_ARM_PER_THREAD - 1) / (JADE_ARM_BLOCK * JADE_ARM_PER_THREAD))), dim3(JADE_ARM_BLOCK), 0, s->stream, s->ps, target_spp,
@@ -2200,6 +2420,7 @@ static int run_passes(jade_scene* s, int64_t from_spp, uint32_t target_spp, bool
     s->host_syncs += 1;
     n_active = host_ctl[1];
   }
+  s->carried_active = 0;
   const uint32_t n_armed = n_active;  // records with work at the start of this call
   int cur = 0, pass_no = 0;
   const bool log_passes = s->tun.log_passes;
@@ -2214,9 +2435,41 @@ static int run_passes(jade_scene* s, int64_t from_spp, uint32_t target_spp, bool
   // JADE_BATCH=0: the host follows every pass (the schedule before batching existed)
   const bool batching = s->tun.batching && !s->sort_rays;  // (rocPRIM wants the queue's length on the host)
   bool closed_by_batch = false;  // the wait at the end of a batch was also the wait for the end of the step
+  // k_tail: once the active list is short - and is not about to be carried over - ONE launch finishes its records (every wave
+  // shades and traces its own 64 until they are out of samples).  The records' last rays have been traced: k_tail starts by shading.
+  const bool tail_ok = s->tun.tail && s->tun.tail_max > 0;
+  const uint32_t tail_max = std::min<uint32_t>(s->tun.tail_max, (uint32_t)(s->b_queue.bytes / 4 / (size_t)std::max(s->ps.nslots, 1)));
   while (n_active) {
     const bool lean_mode = split_ok && (uint64_t)n_active * 4 >= (uint64_t)npix;
-    if (!lean_mode && have_list && batching && !log_passes && pass_no > 0) {
+    if (tail_ok && !lean_mode && have_list && pass_no > 0 && !arm_dev && n_active <= tail_max && !carry_now(n_active)) {
+      TailArgs ta;
+      ta.R = s->rc;
+      ta.tile_ids = s->b_tiles.as<int32_t>();
+      ta.target_spp = target_spp;
+      ta.list = s->b_active[cur].as<uint32_t>();
+      ta.n_list = n_active;
+      ta.queue = s->b_queue.as<uint32_t>();
+      for (hipEvent_t& e : s->ev_tail)
+        if (!e) HIP_TRY(hipEventCreate(&e));
+      HIP_TRY(hipEventRecord(s->ev_tail[0], s->stream));
+      hipLaunchKernelGGL(k_tail, dim3((n_active + JADE_TRACE_BLOCK - 1) / JADE_TRACE_BLOCK), dim3(JADE_TRACE_BLOCK), 0, s->stream, s->dev, s->ps, ta,
+                         s->b_spill.as<uint32_t>(), s->b_ctr.as<DevCounters>());
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipEventRecord(s->ev_tail[1], s->stream));
+      HIP_TRY(hipEventRecord(ev1, s->stream));
+      HIP_TRY(hipStreamSynchronize(s->stream));
+      s->host_syncs += 1;
+      float tt = 0;
+      HIP_TRY(hipEventElapsedTime(&tt, s->ev_tail[0], s->ev_tail[1]));
+      s->tail_ms += tt;
+      s->tail_launches += 1;
+      s->tail_records += n_active;
+      if (log_passes) fprintf(stderr, "[jade] tail: %u records finished by k_tail in %.3f ms\n", n_active, tt);
+      n_active = 0;
+      closed_by_batch = true;  // (ev1 is recorded and waited for)
+      break;
+    }
+    if (!lean_mode && have_list && batching && !log_passes && (pass_no > 0 || arm_dev)) {
       // ---- a BATCH of list-mode passes without the host in between: pass j's k_shade takes its length from the record
       // count pass j-1 left on the device (QueueCtl ring), k_trace sizes its chunks itself; a pass that finds nothing
       // to do is three empty launches.  The host looks once per batch: where the paths ended, whether to carry.
@@ -2229,13 +2482,15 @@ static int run_passes(jade_scene* s, int64_t from_spp, uint32_t target_spp, bool
         const uint64_t b = carry_frac > 0 ? (uint64_t)std::ceil(carry_frac * (double)n_armed) : 0;     // act < carry_frac * n_armed
         stop_below = (uint32_t)std::min<uint64_t>(std::max(a, b), 0xffffffffu);
       }
+      // ... and the point below which k_tail finishes the list: the batch stops there too, the host then launches it (above)
+      if (tail_ok) stop_below = std::max(stop_below, tail_max + 1u);
       for (hipEvent_t& e : s->ev_batch)
         if (!e) HIP_TRY(hipEventCreate(&e));
       HIP_TRY(hipMemsetAsync(qc, 0, sizeof(QueueCtl) * B, s->stream));
       const int cur0 = cur;
       for (int j = 0; j < B; ++j) {
         hipLaunchKernelGGL(k_shade, dim3(nbb), dim3(JADE_SHADE_BLOCK), 0, s->stream, s->dev, s->ps, s->rc, s->b_tiles.as<int32_t>(),
-                           target_spp, s->b_active[cur].as<uint32_t>(), n_active, j ? &qc[j - 1].active : (const uint32_t*)nullptr,
+                           target_spp, s->b_active[cur].as<uint32_t>(), n_active, j ? &qc[j - 1].active : arm_dev,
                            s->b_active[cur ^ 1].as<uint32_t>(), s->b_queue.as<uint32_t>(), qc + j, s->b_ctr.as<DevCounters>(),
                            j ? qc + (j - 1) : (const QueueCtl*)nullptr, stop_below);
         cur ^= 1;
@@ -2291,16 +2546,18 @@ static int run_passes(jade_scene* s, int64_t from_spp, uint32_t target_spp, bool
         launches += 1;
       }
       cur = cur0 ^ (real & 1);  // the list the last pass that ran wrote
+      arm_dev = nullptr;        // (the host has seen a count since)
       if (ended) {
         closed_by_batch = true;
         break;
       }
-      if (stopped || carry_now(n_active)) {
+      if (carry_now(n_active) || (stopped && !(tail_ok && n_active <= tail_max))) {
         s->tail_pending = true;
+        s->carried_active = n_active;
         closed_by_batch = true;
         break;
       }
-      continue;
+      continue;  // (another batch - or, the list being short now, k_tail)
     }
     if (!lean_mode && !have_list) {
       cur = 0;
@@ -2399,6 +2656,13 @@ static int run_passes(jade_scene* s, int64_t from_spp, uint32_t target_spp, bool
       while (tri_bits < 23 && ((uint32_t)(s->dev.n_tris - 1) >> tri_bits)) ++tri_bits;
       hipLaunchKernelGGL(k_ray_keys, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->ps, s->b_queue.as<uint32_t>(), n, s->b_sortkey.as<uint32_t>(),
                          s->n_emit, tri_bits);
+      // The temporary storage was sized once, for (sort_cap entries, bits 0..32).  rocPRIM's need shrinks with the length and with
+      // the bit range (fewer digit places, fewer look-back states; a short queue takes its merge-sort path: two buffers of n), and a
+      // buffer that is too small is an error return, not a fault (rocprim/detail/temp_storage.hpp: partition) - asked again here,
+      // on the host, for THIS length, so that the claim is checked and not assumed ("the round-3 fault").
+      size_t need = 0;
+      HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, 0u, 32u, s->stream));
+      if (need > s->sort_tmp_bytes) return fail(JADE_ERR_DEVICE, "ray-queue sort: temporary storage smaller than rocPRIM asks for this length (internal sizing error)");
       size_t tmp = s->sort_tmp_bytes;
       HIP_TRY(rocprim::radix_sort_pairs(s->b_sorttmp.p, tmp, s->b_sortkey.as<uint32_t>(), s->b_sortkey2.as<uint32_t>(), s->b_queue.as<uint32_t>(),
                                         s->b_sortq.as<uint32_t>(), (size_t)n, 0u, 32u, s->stream));
@@ -2414,6 +2678,7 @@ static int run_passes(jade_scene* s, int64_t from_spp, uint32_t target_spp, bool
       // The few long paths left would take dozens of nearly empty passes: leave them suspended (their
       // rays are traced, their hits wait to be folded in) for the next step's first pass, or for flush.
       s->tail_pending = true;
+      s->carried_active = n_active;
       carried = true;
     }
     if (log_passes) {
@@ -2490,6 +2755,12 @@ static int advance(jade_scene* s, int64_t from0, bool may_carry, jade_stats* st)
     st->rays_inline += c.rays_inline;
     st->nodes_inline += c.nodes_inline;
     st->tris_inline += c.tris_inline;
+    st->rays_cached += c.rays_cached;
+    st->rays_tail += c.rays_tail;
+    st->nodes_tail += c.nodes_tail;
+    st->tris_tail += c.tris_tail;
+    st->tail_ms += s->tail_ms;
+    st->tail_launches += s->tail_launches;
     st->light_ms += s->light_ms;
     st->nodes_visited += c.nodes_visited;
     st->tris_tested += c.tris_tested;
@@ -2502,6 +2773,9 @@ static int advance(jade_scene* s, int64_t from0, bool may_carry, jade_stats* st)
   }
   s->host_syncs = 0;
   s->light_ms = 0;
+  s->tail_ms = 0;
+  s->tail_launches = 0;
+  s->tail_records = 0;
   return JADE_OK;
 }
 
@@ -2544,10 +2818,15 @@ int jade_render_step(jade_scene* s, int32_t spp, jade_stats* st) {
   if (!s || !s->have_rp) return fail(JADE_ERR_INVALID, "jade_render_begin not called");
   if (spp < 0) return fail(JADE_ERR_INVALID, "negative spp");
   HIP_TRY(hipSetDevice(s->device));
+  if (s->ps.npix == 0 || spp == 0) {
+    s->spp_done += spp;
+    return JADE_OK;
+  }
+  // (the sample count moves only once the partial sums have room for the new samples: after a failed grow_sums - out of memory -
+  // a resolve must not divide by samples that were never rendered)
+  if (s->spp_done + spp > s->ps.sum_lanes && s->ps.sum_lanes < JADE_SAMPLE_LANES)
+    if (int rc = grow_sums(s, s->spp_done + spp)) return rc;
   s->spp_done += spp;
-  if (s->ps.npix == 0 || spp == 0) return JADE_OK;
-  if (s->spp_done > s->ps.sum_lanes && s->ps.sum_lanes < JADE_SAMPLE_LANES)
-    if (int rc = grow_sums(s, s->spp_done)) return rc;
   return advance(s, s->spp_done - spp, s->tun.carry, st);
 }
 
@@ -2754,6 +3033,8 @@ int jade_render_multi(jade_scene* const* scenes, int ndev, const jade_render_par
       st->rays_mirror += sts[i].rays_mirror; st->rays_refract += sts[i].rays_refract; st->host_syncs += sts[i].host_syncs;
       st->rays_inline += sts[i].rays_inline;
       st->nodes_inline += sts[i].nodes_inline; st->tris_inline += sts[i].tris_inline;
+      st->rays_cached += sts[i].rays_cached; st->rays_tail += sts[i].rays_tail; st->nodes_tail += sts[i].nodes_tail; st->tris_tail += sts[i].tris_tail;
+      st->tail_ms = std::max(st->tail_ms, sts[i].tail_ms); st->tail_launches += sts[i].tail_launches;
       st->light_ms = std::max(st->light_ms, sts[i].light_ms);
       st->nodes_visited += sts[i].nodes_visited; st->tris_tested += sts[i].tris_tested;
       st->shaded_hits += sts[i].shaded_hits; st->samples += sts[i].samples;
@@ -2767,7 +3048,7 @@ int jade_render_multi(jade_scene* const* scenes, int ndev, const jade_render_par
 // limits (nullable): per ray, the distance below which a recorded hit ends the walk (JADE_WALK_EARLY_EXIT as k_shade asks
 // for it, jade_device.h); null = the reference's walk
 static int trace_rays_impl(jade_scene* s, int32_t n, const float* origins, const float* dirs, const int32_t* skip, const float* limits,
-                           int32_t* hit_index, float* hit_dist, float* hit_point, jade_stats* st) {
+                           int32_t* hit_index, float* hit_dist, float* hit_point, jade_stats* st, bool cached = false) {
   if (!s || n < 0 || !origins || !dirs || !skip || !hit_index) return fail(JADE_ERR_INVALID, "null argument");
   if (n == 0) return JADE_OK;
   HIP_TRY(hipSetDevice(s->device));
@@ -2796,7 +3077,7 @@ static int trace_rays_impl(jade_scene* s, int32_t n, const float* origins, const
   P.nslots = 1;
   P.orgs = b_orgs.as<float4>();
   P.slot = b_slot.as<float4>();
-  P.early_exit = limits ? 1u : 0u;
+  P.early_exit = limits ? (cached ? 2u : 1u) : 0u;
   // everything on the scene's own (non-blocking) stream: the null stream does not order against it
   QueueCtl qc{};
   qc.count = (uint32_t)n;
@@ -2832,6 +3113,7 @@ static int trace_rays_impl(jade_scene* s, int32_t n, const float* origins, const
     st->rays_secondary += (uint64_t)n;
     st->nodes_visited += c.nodes_visited;
     st->tris_tested += c.tris_tested;
+    st->rays_cached += c.rays_cached;
     st->kernel_ms += ms;
     st->trace_ms += ms;
     st->trace_launches += 1;
@@ -2844,6 +3126,12 @@ int jade_trace_rays(jade_scene* s, int32_t n, const float* origins, const float*
   return trace_rays_impl(s, n, origins, dirs, skip, nullptr, hit_index, hit_dist, hit_point, st);
 }
 
+// ---- development / test entry points: NOT part of jade_rt.h and NOT in libjade_hip.so.  Only builds with -DJADE_DEBUG_EXPORTS=1
+// have them: libjade_hip_debug.so (make hipvariants; tests/conftest.py `hip_debug`) and the JADE_TRACE_PROFILE build.
+#ifndef JADE_DEBUG_EXPORTS
+#define JADE_DEBUG_EXPORTS JADE_TRACE_PROFILE
+#endif
+#if JADE_DEBUG_EXPORTS
 // Development / tests (not part of jade_rt.h): jade_trace_rays with a limit per ray - k_trace's early exit on its own, outside
 // the integrator.  For a ray whose nearest hit is not nearer than its limit the answer is the reference's; otherwise it is SOME
 // recorded hit nearer than the limit (which one depends on the schedule of the wave).
@@ -2851,6 +3139,19 @@ int jade_debug_trace_rays_limit(jade_scene* s, int32_t n, const float* origins, 
                                 int32_t* hit_index, float* hit_dist, float* hit_point, jade_stats* st) {
   if (!limits) return fail(JADE_ERR_INVALID, "null argument");
   return trace_rays_impl(s, n, origins, dirs, skip, limits, hit_index, hit_dist, hit_point, st);
+}
+// ... and with the occluder cache (JADE_WALK_EARLY_EXIT_CACHED): a ray with a source triangle and a limit that is not a NaN is a
+// yes/no query keyed by that triangle (query kind: "towards emitter 0", or by octant in a scene without emitters)
+int jade_debug_trace_rays_cached(jade_scene* s, int32_t n, const float* origins, const float* dirs, const int32_t* skip, const float* limits,
+                                 int32_t* hit_index, float* hit_dist, float* hit_point, jade_stats* st) {
+  if (!limits) return fail(JADE_ERR_INVALID, "null argument");
+  return trace_rays_impl(s, n, origins, dirs, skip, limits, hit_index, hit_dist, hit_point, st, true);
+}
+// whether jade_scene_create found every child's box inside its parent's (1), what the wide walk and the occluder cache rest on; and
+// whether the scene got wide records (bit 1) / an occluder cache (bit 2)
+int jade_debug_scene_flags(jade_scene* s) {
+  if (!s) return -1;
+  return (s->boxes_nested ? 1 : 0) | (s->dev.nodes4 ? 2 : 0) | (s->dev.anyhit ? 4 : 0);
 }
 
 // Development / tests (not part of jade_rt.h): shadow_limit (jade_shade.h) for n rays against triangle tri (BVH order): what
@@ -2930,5 +3231,6 @@ int jade_debug_trace_profile(unsigned long long* out, int n, int reset) {
   return -fail(JADE_ERR_UNSUPPORTED, "not a JADE_TRACE_PROFILE build");
 #endif
 }
+#endif  // JADE_DEBUG_EXPORTS
 
 }  // extern "C"

@@ -734,7 +734,30 @@ static_assert((JADE_HQ & (JADE_HQ - 1)) == 0 && JADE_HQ >= 128, "JADE_HQ");
 #endif
 #define JADE_CUT 0x40000000u          /* WalkState.skipx: the ray has its answer (early exit) */
 #define JADE_FORCE_BINARY 0x20000000u /* ... this ray takes binary units only (it is being walked again after a tie, "Wide walk") */
-#define JADE_SKIP_MASK 0x1fffffffu    /* ... its source triangle (all ones = none; triangle indices stay below 2^27) */
+#define JADE_ATTEMPT 0x10000000u      /* ... the walk in progress covers the cached subtrees only ("Occluder cache" below): without an answer the whole walk follows */
+#define JADE_SKIP_MASK 0x0fffffffu    /* ... its source triangle (all ones = none; triangle indices stay below 2^27 / 3) */
+
+// ---------------------------------------------------------------------------------------------------------------
+// Occluder cache (round 4; jade_render_params.walk == JADE_WALK_EARLY_EXIT_CACHED).  A shadow or environment-visibility query only
+// asks whether SOME triangle the reference's walk tests is hit below the query's limit.  Which triangles the
+// reference tests does not depend on order: a leaf is reached iff the ray meets its box and every ancestor's, and - boxes nested,
+// hitAABB monotone (3.3c; jade_scene_create checks the nesting) - a leaf whose own box is met is reached.  So a walk may START
+// anywhere: walking the subtree under an internal node X tests X's children's boxes as the reference does, every leaf it reaches
+// is one the reference reaches, and a hit below the limit found there settles the query exactly as it would have later.  Such
+// queries repeat: from one source triangle towards one emitter (or into one octant of the sky) the occluder is mostly the same
+// piece of geometry - the floor under the statue, the statue's other side.  The module keeps, per (source triangle, query kind),
+// four internal-node references: the parents of the leaves in which the last whole walks of such queries found their answer
+// (a pair record carries its leaf's parent in the upper bits of its flag word, so the walk learns it from the record it re-reads
+// for the result anyway).  A query first walks those subtrees (JADE_ATTEMPT: the lane's stack starts with them instead of the
+// root - the same units of work, nothing new in the loop); with an answer it is done, without one it is walked again from the
+// root and, if that walk ends early, its leaf's parent replaces one of the four.  Measured on the oracle first
+// (tools/anyhit_probe.py, profiles/r04_anyhit_probe_oracle.txt): 70 % of C3's occluded shadow queries and 96 % of its occluded
+// environment queries are answered by the cached subtrees, -60 % / -85 % node records for those queries.
+// What it does NOT change: any answer (the frame, the rays, the samples: asserted bit for bit against the reference walk).  What
+// it does change: nodes_visited / tris_tested - they count what was read, and with a cache shared by all waves they are no
+// longer the same from run to run.
+// ---------------------------------------------------------------------------------------------------------------
+#define JADE_ANYHIT_KEYS 10 /* per source triangle: shadow query towards emitter 0 / another emitter, environment query by the octant of its direction */
 struct WalkState {
 #if JADE_PREFETCH
   NodeRec pre;      // the record of `cur`, requested when cur was set
@@ -768,6 +791,20 @@ static __device__ __forceinline__ void walk_begin(WalkState& r, const LdsStack& 
   lds_put(stk, TW_BEST_REF, 0xffffffffu);
   lds_st_v(stk.col + TW_FINISHED * JADE_COL_STRIDE, 0u);
   lds_putf(stk, TW_LIMIT, limit);
+#if JADE_PREFETCH
+  r.pre = node_fetch<JADE_TRACE_TOP_NODES>(r.cur, S, stk);
+#endif
+}
+// The same ray once more, from the root, with nothing found yet (k_trace: an attempt over the cached subtrees that found no answer;
+// a wide walk that met a tie).  The ray itself - origin, directions, source triangle, its limit in the column - stays as it is.
+static __device__ __forceinline__ void walk_restart(WalkState& r, const LdsStack& stk, const DevScene& S) {
+  r.sp = stk.col;
+  r.pushed = 0;
+  r.cur = S.root_ref;
+  lds_putf(stk, TW_BEST_DIST, JADE_INF_F);
+  lds_put(stk, TW_BEST_SEQ, 0xffffffffu);
+  lds_put(stk, TW_BEST_REF, 0xffffffffu);
+  lds_st_v(stk.col + TW_FINISHED * JADE_COL_STRIDE, 0u);
 #if JADE_PREFETCH
   r.pre = node_fetch<JADE_TRACE_TOP_NODES>(r.cur, S, stk);
 #endif
@@ -853,15 +890,19 @@ static __device__ __forceinline__ void resolve_hit(uint32_t ref, uint32_t meta, 
   __hip_atomic_fetch_add((jade_lds_u32*)(__SIZE_TYPE__)(ocol + TW_FINISHED * JADE_COL_STRIDE), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 // The hit a finished ray reports: triangle index (-1 = miss), distance and hit point of the winning triangle.
-static __device__ __forceinline__ int32_t walk_result(const LdsStack& stk, const DevScene& S, const RayOD& od, float* dist, jvec3* P) {
+// parent1: the winning triangle's leaf's parent + 1 (the pair record's flag word, bits 1-31; 0 = none, or no hit)
+static __device__ __forceinline__ int32_t walk_result(const LdsStack& stk, const DevScene& S, const RayOD& od, float* dist, jvec3* P, uint32_t* parent1 = nullptr) {
   const uint32_t ref = lds_get(stk, TW_BEST_REF);
   *dist = lds_getf(stk, TW_BEST_DIST);
+  if (parent1) *parent1 = 0u;
   if (ref == 0xffffffffu) return -1;
   const float4* t0 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.tverts) + (ref & 0x7ffffff0u));
   const int k = (int)(ref & 1u);
   float d2;
   pair_hit(t0, k, od, &d2, P);
-  return (int32_t)(jade_f2u(t0[4].z) + (uint32_t)k);
+  const float4 tag = t0[4];
+  if (parent1) *parent1 = jade_f2u(tag.w) >> 1;
+  return (int32_t)(jade_f2u(tag.z) + (uint32_t)k);
 }
 
 // JADE_COST_NODE / JADE_COST_TRI: instructions issued by a walk unit / a test unit (the kind that advances more lanes

@@ -59,7 +59,7 @@ static void usage() {
           "                   [--out file.bmp|.ppm|.pfm] [--env sky|file.hdr] [--backend lib.so] [--device N] [--reference-walk]\n"
           "  --reference-walk: every hitBVH query walks what the reference walks (nodes_visited / tris_tested equal the oracle's);\n"
           "                    default: shadow / environment-visibility walks end at the hit that settles them - the same image, bit for bit\n"
-          "  NAME: tiny, tinyjade, C1, C2, C3, C4, C5 (SURVEY.md section 8d)\n");
+          "  NAME: tiny, tinyjade, C1, C2, C3, C4, C5 (SURVEY.md section 8d); C3G = C3 with a DIR_REFRACT glass statue\n");
 }
 
 int main(int argc, char** argv) {

@@ -300,12 +300,24 @@ static void add_cornell(SceneBuilder& b, int sphere_freq) {
   b.add_mesh(ball, white, transform_matrix(rot0, tB, sB), false);
 }
 
-static void add_jade_scene(SceneBuilder& b, const Mesh& statue, bool dragon) {
+// DIR_REFRACT (refract_mode 2, PathTrace.cpp:34, PathTrace.cu:1180-1262): the third material mode, which none of the reference's
+// own scenes uses for the statue - a glass of index 1.5 that tints what passes through it (rate^distance, :1213)
+static Material glass_material() {
+  Material m;
+  for (int k = 0; k < 3; ++k) { m.brdf[k] = 0.05f; m.refract_albedo[k] = 0.3f; }
+  m.refract_rate[0] = 0.9f; m.refract_rate[1] = 0.95f; m.refract_rate[2] = 0.9f;
+  m.reflex_mode = JADE_MIRROR;
+  m.refract_mode = JADE_DIR_REFRACT;
+  m.refract_index = 1.5f;
+  return m;
+}
+
+static void add_jade_scene(SceneBuilder& b, const Mesh& statue, bool dragon, bool glass = false) {
   // PathTrace.cpp:1002-1037: statue, light quad, mirror floor box.  The dragon
   // uses the commented-out loong.obj placement (PathTrace.cpp:992).
   const float rS[3] = {-90, 0, 0}, tS[3] = {0, -0.52f, 0.5f}, sS[3] = {0.3f, 0.3f, 0.3f};
   const float rD[3] = {0, 0, 0}, tD[3] = {0.1f, -0.5f, 0.0f}, sD[3] = {0.7f, 0.7f, 0.7f};
-  b.add_mesh(statue, jade_material(), dragon ? transform_matrix(rD, tD, sD) : transform_matrix(rS, tS, sS), true);
+  b.add_mesh(statue, glass ? glass_material() : jade_material(), dragon ? transform_matrix(rD, tD, sD) : transform_matrix(rS, tS, sS), true);
   Material light = diffuse_material(0.3f, 0.3f, 0.3f);
   for (int k = 0; k < 3; ++k) light.emissive[k] = 1000.0f;
   const float rL[3] = {0, 90, 90}, tL[3] = {-0.2f, 1.2f, 1.0f}, sL[3] = {1.5f, 0.5f, 1.5f};
@@ -346,8 +358,10 @@ bool make_config(const std::string& name, SceneBuilder& b, Config& cfg, std::str
     camera_orbit(0.8f, 8.0f, 10.0f, ctr, cfg.eye, cfg.camera);
     return true;
   }
-  if (name == "C2" || name == "C3" || name == "C4") {
-    add_jade_scene(b, make_statue(59, 20211013u, 0), false);  // 20*59^2 = 69,620 triangles
+  if (name == "C2" || name == "C3" || name == "C4" || name == "C3G") {
+    // C3G: C3's geometry, camera and frame with the statue made of DIR_REFRACT glass instead of jade - the serial chain of up to
+    // 32 internal reflections / refractions per sample (PathTrace.cu:1180-1262) that no BASELINE config exercises
+    add_jade_scene(b, make_statue(59, 20211013u, 0), false, name == "C3G");  // 20*59^2 = 69,620 triangles
     b.set_env(make_env_sky(1024, 512));
     if (name == "C2") { cfg.width = cfg.height = 512; cfg.spp = 256; }
     else { cfg.width = 1920; cfg.height = 1080; cfg.spp = 4096; }
@@ -366,7 +380,7 @@ bool make_config(const std::string& name, SceneBuilder& b, Config& cfg, std::str
     camera_orbit(1.3f, 14.0f, 25.0f, ctr, cfg.eye, cfg.camera);
     return true;
   }
-  err = "unknown config '" + name + "' (tiny, tinyjade, C1, C2, C3, C4, C5)";
+  err = "unknown config '" + name + "' (tiny, tinyjade, C1, C2, C3, C3G, C4, C5)";
   return false;
 }
 

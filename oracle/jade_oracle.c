@@ -285,12 +285,162 @@ static HitResult hit_bvh_pruned(const jade_scene* s, Ray ray, int src_object_idx
   return res;
 }
 
+
+/* Round 4 probe (mode 5; diagnostics only, NOT the reference's algorithm): what do the early-exit queries cost by kind and by
+ * outcome, and what would they cost with (a) a cache, per (source triangle, query), of where the last such query found its answer
+ * - the triangle itself, or the subtree `up` levels above its leaf, walked first - and (b) the larger child first instead of the
+ * nearer?  Everything a cached attempt tests is something the reference's walk tests too (boxes are nested, hit_aabb is monotone:
+ * a leaf whose box the ray meets is reached by the reference), so an answer found there is exact; an attempt that finds none is
+ * followed by the whole walk.  jade_oracle_set_prune(5, up, flags, ways): up < 0 = no cache, 0 = the triangle, k > 0 = k levels above the leaf;
+ * flags bit 0 = larger child first, bit 1 = the cached subtree's leaves are not tested again by the whole walk (not modelled: 0). */
+static uint64_t g_kind_ctr[4][2][5]; /* [kind: other, shadow, env, indirect][answered early: no, yes][calls, internal pops, leaves, tests, cache answers] */
+void jade_oracle_kind_counters(uint64_t* out, int reset) {
+  memcpy(out, g_kind_ctr, sizeof g_kind_ctr);
+  if (reset) memset(g_kind_ctr, 0, sizeof g_kind_ctr);
+}
+#define OCC_KEYS 10 /* per source triangle: emitter 0, emitter 1+, environment query by octant */
+#define OCC_WAYS 4
+static int32_t* g_occ; /* [n_tris + 1][OCC_KEYS][OCC_WAYS] where the last such queries found their answer (triangle or node), -1 = none */
+static int32_t* g_tri_leaf; /* triangle -> its leaf node */
+static int32_t* g_parent;   /* node -> parent */
+static const jade_scene* g_occ_scene;
+static pthread_mutex_t g_occ_mu = PTHREAD_MUTEX_INITIALIZER;
+void jade_oracle_occ_reset(void) {
+  pthread_mutex_lock(&g_occ_mu);
+  g_occ_scene = NULL;
+  pthread_mutex_unlock(&g_occ_mu);
+}
+static void occ_prepare(const jade_scene* s) {
+  if (__atomic_load_n(&g_occ_scene, __ATOMIC_ACQUIRE) == s) return;
+  pthread_mutex_lock(&g_occ_mu);
+  if (g_occ_scene != s) {
+    free(g_occ); free(g_tri_leaf); free(g_parent);
+    const int nt = s->d.n_triangles;
+    const size_t n = (size_t)(nt + 1) * OCC_KEYS * OCC_WAYS;
+    g_occ = (int32_t*)malloc(sizeof(int32_t) * n);
+    for (size_t i = 0; i < n; ++i) g_occ[i] = -1;
+    g_tri_leaf = (int32_t*)calloc((size_t)nt, sizeof(int32_t));
+    g_parent = (int32_t*)calloc((size_t)s->d.n_nodes, sizeof(int32_t));
+    for (int k = 1; k < s->d.n_nodes; ++k) {
+      if (s->nodes[k].n > 0) { for (int i = 0; i < s->nodes[k].n; ++i) g_tri_leaf[s->nodes[k].index + i] = k; }
+      else { if (s->nodes[k].left > 0) g_parent[s->nodes[k].left] = k; if (s->nodes[k].right > 0) g_parent[s->nodes[k].right] = k; }
+    }
+    __atomic_store_n(&g_occ_scene, s, __ATOMIC_RELEASE);
+  }
+  pthread_mutex_unlock(&g_occ_mu);
+}
+static float box_area(const jade_bvh_node* n) {
+  const float dx = n->bb[0] - n->aa[0], dy = n->bb[1] - n->aa[1], dz = n->bb[2] - n->aa[2];
+  return dx * dy + dy * dz + dz * dx;
+}
+/* the walk from `root` (its own box not tested), ended early by a recorded hit below `limit` (limit < 0: never) */
+static int walk_from(const jade_scene* s, Ray ray, int src, counters* c, int root, float limit, int area_first, HitResult* res, uint64_t* ni, uint64_t* nl) {
+  int stack[JADE_BVH_STACK_CAPACITY];
+  int sp = 0;
+  stack[sp++] = root;
+  while (sp > 0) {
+    --sp;
+    const jade_bvh_node* node = &s->nodes[stack[sp]];
+    if (node->n > 0) {
+      ++*nl;
+      HitResult r = hit_array(s, ray, node->index, node->index + node->n - 1, src, c);
+      if (r.isHit && r.distance < res->distance) *res = r;
+      if (limit >= 0 && res->isHit && res->distance < limit) return 1;
+      continue;
+    }
+    ++*ni;
+    float d1 = -1, d2 = -1;
+    if (node->left > 0) d1 = hit_aabb(ray, V3(s->nodes[node->left].aa), V3(s->nodes[node->left].bb));
+    if (node->right > 0) d2 = hit_aabb(ray, V3(s->nodes[node->right].aa), V3(s->nodes[node->right].bb));
+    if (d1 > 0 && d2 > 0) {
+      int left_first = d1 < d2;
+      if (area_first) left_first = box_area(&s->nodes[node->left]) >= box_area(&s->nodes[node->right]);
+      if (left_first) { stack[sp++] = node->right; stack[sp++] = node->left; }
+      else { stack[sp++] = node->left; stack[sp++] = node->right; }
+    } else if (d1 > 0) stack[sp++] = node->left;
+    else if (d2 > 0) stack[sp++] = node->right;
+  }
+  return 0;
+}
+static HitResult hit_bvh_anyhit(const jade_scene* s, Ray ray, int src_object_idx, counters* c) {
+  HitResult res;
+  res.isHit = 0; res.index = 0; res.distance = INF_F; res.hitPoint = jv(0, 0, 0);
+  static __thread uint64_t seen_shadow, seen_env, seen_ind;
+  int kind = 0, stat_kind = 0;
+  if (c->rays_shadow != seen_shadow) { kind = 1; seen_shadow = c->rays_shadow; }
+  else if (c->rays_env != seen_env) { kind = 2; seen_env = c->rays_env; }
+  else if (c->rays_indirect != seen_ind) { stat_kind = 3; seen_ind = c->rays_indirect; }
+  if (kind) stat_kind = kind;
+  float limit = -1.0f; /* < 0: the nearest hit is wanted */
+  int key = 0;
+  const int up = (int)g_prune_rel, flags = (int)g_prune_abs;
+  if (kind == 1) {
+    limit = INF_F;
+    float d_e = -1.0f;
+    for (int i = 0; i < s->d.n_emit; ++i) {
+      HitResult h = hit_triangle(&s->tris[s->emit[i]], ray, s->emit[i]);
+      if (h.isHit && (d_e < 0 || h.distance < d_e)) { d_e = h.distance; key = i < 1 ? 0 : 1; }
+    }
+    if (d_e > 0) limit = d_e;
+  } else if (kind == 2) {
+    limit = INF_F;
+    const int oct = (ray.direction.x < 0) | ((ray.direction.y < 0) << 1) | ((ray.direction.z < 0) << 2);
+    key = 2 + ((flags & 4) ? 0 : (flags & 8) ? (ray.direction.y < 0) : oct); /* flags bit 2: one key for all environment queries; bit 3: by the sign of d.y */
+  }
+  uint64_t ni = 0, nl = 0, nt0 = c->tris_tested, cache_answer = 0;
+  int ways = (int)g_prune_minz; if (ways < 1) ways = 1; if (ways > OCC_WAYS) ways = OCC_WAYS;
+  const int use_cache = up >= 0 && kind != 0;
+  const int area_first = (flags & 1) && kind != 0;
+  int32_t* slot = NULL;
+  int early = 0;
+  if (use_cache) {
+    occ_prepare(s);
+    slot = &g_occ[((size_t)(src_object_idx < 0 ? s->d.n_triangles : src_object_idx) * OCC_KEYS + key) * OCC_WAYS];
+    for (int w = 0; w < ways && !early; ++w) {
+      const int32_t t = slot[w];
+      if (t < 0) continue;
+      if (up == 0) {
+        if (t == src_object_idx) continue;
+        const jade_bvh_node* leaf = &s->nodes[g_tri_leaf[t]];
+        if (hit_aabb(ray, V3(leaf->aa), V3(leaf->bb)) > 0) { /* nested boxes: the reference's walk reaches this leaf */
+          c->tris_tested++;
+          HitResult h = hit_triangle(&s->tris[t], ray, t);
+          if (h.isHit && h.distance < limit) { res = h; early = 1; }
+        }
+      } else {
+        /* (a cached leaf - a tree of one leaf - needs its own box tested; an internal node's children are tested by the walk) */
+        if (s->nodes[t].n > 0 && !(hit_aabb(ray, V3(s->nodes[t].aa), V3(s->nodes[t].bb)) > 0)) continue;
+        HitResult r2 = res;
+        if (walk_from(s, ray, src_object_idx, c, t, limit, 0, &r2, &ni, &nl)) { res = r2; early = 1; }
+      }
+      if (early) { cache_answer = 1; if (w) { const int32_t x = slot[w]; for (int j = w; j > 0; --j) slot[j] = slot[j - 1]; slot[0] = x; } }
+    }
+  }
+  if (!early) {
+    res.isHit = 0; res.index = 0; res.distance = INF_F;
+    early = walk_from(s, ray, src_object_idx, c, 1, limit, area_first, &res, &ni, &nl);
+    if (use_cache && early) {
+      int32_t v = res.index;
+      if (up > 0) { v = g_tri_leaf[res.index]; for (int j = 0; j < up && g_parent[v] > 1; ++j) v = g_parent[v]; }
+      for (int j = ways - 1; j > 0; --j) slot[j] = slot[j - 1];
+      slot[0] = v;
+    }
+  }
+  uint64_t* k = g_kind_ctr[stat_kind][early];
+  __sync_fetch_and_add(&k[0], 1);
+  __sync_fetch_and_add(&k[1], ni);
+  __sync_fetch_and_add(&k[2], nl);
+  __sync_fetch_and_add(&k[3], c->tris_tested - nt0);
+  __sync_fetch_and_add(&k[4], cache_answer);
+  return res;
+}
 #endif /* JADE_ORACLE_PROBE */
 
 /* PathTrace.cu:795-859 */
 static HitResult hit_bvh(const jade_scene* s, Ray ray, int src_object_idx, counters* c) {
 #ifdef JADE_ORACLE_PROBE
-  if (g_prune_mode) return hit_bvh_pruned(s, ray, src_object_idx, c); /* (the probe build only, see above) */
+  if (g_prune_mode >= 5) return hit_bvh_anyhit(s, ray, src_object_idx, c); /* (the probe build only, see above) */
+  if (g_prune_mode) return hit_bvh_pruned(s, ray, src_object_idx, c);
 #endif
   HitResult res;
   res.isHit = 0;
@@ -1036,6 +1186,13 @@ int jade_oracle_set_tile_filter(jade_scene* s, const int32_t* tile_ids, int32_t 
   free(s->tile_keep);
   s->tile_keep = NULL;
   s->tile_keep_n = 0;
+  /* the sums of a render in progress were laid out for the old filter (sum_slot): that render is over - the next step needs a
+   * new jade_render_begin (a filter changed between begin and step indexed the compact sums with -1) */
+  s->have_rp = 0;
+  free(s->sum);
+  s->sum = NULL;
+  free(s->sum_slot);
+  s->sum_slot = NULL;
   if (n == 0) return JADE_OK;
   int32_t mx = -1;
   for (int i = 0; i < n; ++i) {

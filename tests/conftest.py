@@ -50,6 +50,15 @@ def hip():
     return be
 
 
+@pytest.fixture(scope="session")
+def hip_debug(hip):
+    """libjade_hip_debug.so: the product's sources built with -DJADE_DEBUG_EXPORTS=1 (make hipvariants) - the same kernels plus the
+    jade_debug_* entry points the piece-by-piece tests call.  libjade_hip.so itself exports none of them (tests/test_abi.py)."""
+    path = os.path.join(ROOT, "jaderaytracerendering_amd", "lib", "libjade_hip_debug.so")
+    assert os.path.exists(path), "libjade_hip_debug.so missing: run `make hipvariants` (or __graft_entry__.build())"
+    return B.Backend(path)
+
+
 _scene_cache = {}
 
 
@@ -88,6 +97,23 @@ def assert_early_exit_equals_reference_walk(ref, early, fewer=True):
     assert {k: v for k, v in c0.items() if k not in WALK_KEYS} == {k: v for k, v in c1.items() if k not in WALK_KEYS}
     for k in WALK_KEYS:
         assert not fewer or c1[k] <= c0[k], k
+
+
+def assert_cached_walk_equals_reference_walk(sc, params, ref, renders=2):
+    """JADE_WALK_EARLY_EXIT_CACHED (jade_rt.h, ABI 7): yes/no queries first walk the subtrees in which earlier such queries found
+    their answer.  Rendered `renders` times on the same scene handle - the first with a cold cache (or whatever an earlier render of
+    this scene left in it), the next ones with what the first one learnt - every frame must be the reference walk's bit for bit,
+    with every ray / sample / vertex count; node records and triangle tests may be anything (they count what was read, and a failed
+    attempt is read twice).  Returns the last render."""
+    from jaderaytracerendering_amd import _abi
+    q = type(params).from_buffer_copy(params)
+    q.walk = _abi.WALK_EARLY_EXIT_CACHED
+    out = None
+    for _ in range(renders):
+        out = sc.render(q)
+        assert_early_exit_equals_reference_walk(ref, out, fewer=False)
+        assert out[2].rays_cached <= out[2].rays_shadow + out[2].rays_env
+    return out
 
 
 @pytest.fixture(scope="session")

@@ -112,3 +112,18 @@ def test_abi_version_is_single_sourced():
     assert int(re.search(r"#define JADE_SAMPLE_LANES (\d+)", text).group(1)) == _abi.JADE_SAMPLE_LANES
     for path in (B.HIP_LIB, os.path.join(ROOT, "oracle", "libjade_oracle.so")):
         assert ctypes.CDLL(path).jade_abi_version() == ver, path
+
+
+def test_product_library_exports_only_the_boundary():
+    """libjade_hip.so's dynamic symbols named jade_* are exactly what include/jade_rt.h and include/jade_bvh.h declare: the
+    jade_debug_* entry points the piece-by-piece GPU tests use live in libjade_hip_debug.so."""
+    import subprocess
+    path = os.path.join(ROOT, "jaderaytracerendering_amd", "lib", "libjade_hip.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in out.splitlines() if line.split()[-1].startswith("jade_")}
+    declared = _declared_symbols("jade_rt.h") | _declared_symbols("jade_bvh.h")
+    assert exported - declared <= {"jade_fail"}, sorted(exported - declared)  # (jade_fail: shared by the module's two translation units)
+    assert declared <= exported
+    dbg = os.path.join(ROOT, "jaderaytracerendering_amd", "lib", "libjade_hip_debug.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", dbg], capture_output=True, text=True, check=True).stdout
+    assert "jade_debug_trace_rays_limit" in out and "jade_debug_trace_rays_cached" in out

@@ -22,7 +22,86 @@ def test_counter_file_belongs_to_the_tree():
     """The committed per-ray counters were cut from this build of csrc/ (tools/summarize_prof.py): the driver's bench line then
     carries roofline fractions instead of nulls."""
     ctr = json.load(open(os.path.join(ROOT, "profiles", "k_trace_counters.json")))
-    assert ctr["csrc_sha"] == bench.csrc_hash(), "csrc/ changed since profiles/k_trace_counters.json was cut: re-run tools/profile_r03.sh + tools/summarize_prof.py"
+    assert ctr["csrc_sha"] == bench.csrc_hash(), "csrc/ changed since profiles/k_trace_counters.json was cut: re-run tools/r04.sh profile <tag> C5, then tools/summarize_prof.py <tag>"
     for key in ("C3", "C5"):
         e = ctr[key]
         assert e["valu_lane_ops_per_ray"] > 0 and e["l2_requests_per_ray"] > 0 and e["hbm_bytes_per_ray"] > 0 and e["fetch_size_factor"] == 1.0
+
+
+# ---- the two ways bench.py is started on more than one GPU (VERDICT r3 item 1) -----------------------------------------------
+# The driver starts it under `python -m torch.distributed.run` (one rank per GPU) and sets nothing in the environment; started by
+# hand with --gpus N it spawns that launcher itself.  Either way every rank must (a) have HSA_ENABLE_IPC_MODE_LEGACY=0 in its
+# environment before torch / HIP are loaded (RCCL's bootstrap fails without it on this pool's host driver), (b) rendezvous on
+# 127.0.0.1 and (c) own the tiles (tx + ty) % N == rank with N x 1024 samples per step.  JADE_BENCH_PLUMBING_ONLY makes a rank
+# print that plumbing and return before it imports torch: no GPU is needed, so the launch forms are covered here.
+import socket  # noqa: E402
+import subprocess  # noqa: E402
+import sys  # noqa: E402
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _ranks(cmd, extra_env=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("HSA_ENABLE_IPC_MODE_LEGACY", "MASTER_ADDR", "RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["JADE_BENCH_PLUMBING_ONLY"] = "1"
+    env.update(extra_env or {})
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    recs = [json.loads(line) for line in out.stdout.splitlines() if line.startswith("{")]
+    return sorted(recs, key=lambda r: r["rank"])
+
+
+def _check_world(recs, world):
+    from jaderaytracerendering_amd import distributed as D
+    assert [r["rank"] for r in recs] == list(range(world))
+    tx, ty = D.tile_grid(1920, 1080)
+    assert sum(r["owned_tiles"] for r in recs) == tx * ty
+    for r in recs:
+        assert r["world"] == world and r["gpus"] == world and r["local_rank"] == r["rank"]
+        assert r["HSA_ENABLE_IPC_MODE_LEGACY"] == ("0" if world > 1 else None)
+        assert r["spp_per_step"] == 1024 * world and r["steps"] == 3 and r["warmup"] == 1
+        assert not r["torch_loaded"], "the environment must be prepared before torch is imported"
+        ids = D.owned_tile_ids(1920, 1080, r["rank"], world)
+        assert r["owned_tiles"] == len(ids) and r["first_tiles"] == [int(t) for t in ids[:4]]
+        if world > 1:
+            assert r["MASTER_ADDR"] == "127.0.0.1"
+
+
+def test_driver_style_launch_prepares_every_rank():
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 ... bench.py --gpus 2 ...`: the driver's form."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
+    _check_world(_ranks(cmd), 2)
+
+
+def test_self_spawned_launch_equals_the_driver_style_one():
+    """`python bench.py --gpus 2` with no launcher spawns the same launcher as a child: the same ranks, tiles and environment."""
+    a = _ranks([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"])
+    _check_world(a, 2)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
+    b = _ranks(cmd)
+    drop = lambda r: {k: v for k, v in r.items() if k != "MASTER_ADDR"}  # noqa: E731
+    assert [drop(r) for r in a] == [drop(r) for r in b]
+
+
+def test_one_rank_under_the_launcher_equals_the_plain_launch():
+    """--gpus 1 started under torch.distributed.run (WORLD_SIZE=1) is the plain `python bench.py`: same tiles, same samples, and
+    no multi-rank environment is forced on it."""
+    plain = _ranks([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1"])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1"]
+    launched = _ranks(cmd)
+    _check_world(plain, 1)
+    _check_world(launched, 1)
+    drop = lambda r: {k: v for k, v in r.items() if k != "MASTER_ADDR"}  # noqa: E731
+    assert [drop(r) for r in plain] == [drop(r) for r in launched]
+
+
+def test_an_operators_own_ipc_setting_is_kept():
+    recs = _ranks([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"], {"HSA_ENABLE_IPC_MODE_LEGACY": "1"})
+    assert [r["HSA_ENABLE_IPC_MODE_LEGACY"] for r in recs] == ["1", "1"]

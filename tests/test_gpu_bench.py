@@ -48,8 +48,10 @@ def test_bench_json_contract():
     assert kt["nodes_per_ray"] > 0 and kt["tris_per_ray"] >= 0 and kt["algorithmic_bytes_per_ray"] > 0
     # the timed region runs with early exits (jade_rt.h, JADE_WALK_EARLY_EXIT); the same steps with the reference's walk are
     # measured beside it, and the algorithmic bytes are those of the reference's walk, not of what was read
+    # (the side run has the timed region's own step and warm-up counts)
     rw = d["reference_walk"]
-    assert d["config"]["walk"] == "early_exit" and rw["value"] > 0 and rw["steps"] == 2 and d["value_reference_walk"] == rw["value"]
+    assert d["config"]["walk"] == "early_exit" and rw["value"] > 0 and rw["steps"] == 2 and rw["warmup"] == 1 and d["value_reference_walk"] == rw["value"]
+    assert d["value_early_exit_walk"] == d["value"] and d["early_exit_walk"] is None and d["occluder_cache"] is None
     assert rw["nodes_per_ray_k_trace"] >= kt["nodes_per_ray"] and rw["tris_per_ray_k_trace"] >= kt["tris_per_ray"]
     assert abs(kt["algorithmic_bytes_per_ray"] - (40 * rw["nodes_per_ray_k_trace"] + 36 * rw["tris_per_ray_k_trace"])) < 1e-6 * kt["algorithmic_bytes_per_ray"]
     # the frame the run rendered, against the oracle on a few tiles at the full sample count
@@ -62,6 +64,18 @@ def test_bench_json_contract():
     assert cb["kind"] == "port" and cb["unit"] == "Mray/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
     # samples rendered in the timed region: 2 steps x 16 spp x 96 x 64 pixels
     assert d["samples"] == 2 * 16 * 96 * 64
+
+
+def test_bench_with_the_occluder_cache():
+    """bench.py --walk cached: JADE_WALK_EARLY_EXIT_CACHED in the timed region, both other walks beside it; the frame is checked
+    against the oracle like any other (parity_check)."""
+    d = _bench_line(["--config", "tinyjade", "--width", "96", "--height", "64", "--spp-per-step", "16", "--steps", "2", "--warmup", "1",
+                     "--cpu-spp", "1", "--walk", "cached"])
+    rw, ew, oc = d["reference_walk"], d["early_exit_walk"], d["occluder_cache"]
+    assert d["config"]["walk"] == "cached" and rw["value"] > 0 and ew["value"] > 0 and d["value_early_exit_walk"] == ew["value"]
+    assert rw["nodes_per_ray_k_trace"] >= ew["nodes_per_ray_k_trace"] and rw["tris_per_ray_k_trace"] >= ew["tris_per_ray_k_trace"]
+    assert 0 <= oc["answered"] <= d["rays_by_call_site"]["shadow"] + d["rays_by_call_site"]["env"] and 0 <= oc["share_of_shadow_and_env_rays"] <= 1
+    assert d["parity_check"]["ok"] is True
 
 
 def _bench_line(args, timeout=900):

@@ -14,7 +14,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import B, J, assert_early_exit_equals_reference_walk, config_scene, counters, rel_l2, WALK_KEYS
+from conftest import B, J, assert_cached_walk_equals_reference_walk, assert_early_exit_equals_reference_walk, config_scene, counters, rel_l2, WALK_KEYS
 from jaderaytracerendering_amd import _abi
 
 pytestmark = pytest.mark.gpu
@@ -22,7 +22,7 @@ INF = np.float32(2147483647.0)
 
 
 def _shadow_limit(hip, sc, o, d, tri):
-    fn = hip.lib.jade_debug_shadow_limit  # development export of libjade_hip.so (not part of jade_rt.h)
+    fn = hip.lib.jade_debug_shadow_limit  # libjade_hip_debug.so only (not part of jade_rt.h)
     fn.restype = C.c_int
     fn.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 4
     out = np.zeros(len(o), np.float32)
@@ -30,8 +30,8 @@ def _shadow_limit(hip, sc, o, d, tri):
     return out
 
 
-def _trace_limit(hip, sc, o, d, skip, limit):
-    fn = hip.lib.jade_debug_trace_rays_limit  # development export (not part of jade_rt.h)
+def _trace_limit(hip, sc, o, d, skip, limit, cached=False):
+    fn = hip.lib.jade_debug_trace_rays_cached if cached else hip.lib.jade_debug_trace_rays_limit  # libjade_hip_debug.so only (not part of jade_rt.h)
     fn.restype = C.c_int
     fn.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 8
     n = len(o)
@@ -66,9 +66,10 @@ def _aimed_rays(hs, n, seed):
 
 
 @pytest.mark.parametrize("name", ["tinyjade", "C1", "C2"])
-def test_shadow_limit_is_the_walks_own_distance(oracle, hip, name):
+def test_shadow_limit_is_the_walks_own_distance(oracle, hip_debug, name):
     """Wherever the walk's nearest hit IS the target, its distance and the limit are the same float; a limit is never a value
     the walk could not have recorded (0 < limit <= INF); and a target the ray misses gives INF."""
+    hip = hip_debug  # (the same kernels + the jade_debug_* entry points)
     hs, _ = config_scene(name)
     o, d, skip, tri = _aimed_rays(hs, 30000, 5)
     with oracle.scene(hs) as so, hip.scene(hs) as sh:
@@ -87,9 +88,10 @@ def test_shadow_limit_is_the_walks_own_distance(oracle, hip, name):
 
 @pytest.mark.parametrize("wide", ["0", "1"])
 @pytest.mark.parametrize("name", ["tinyjade", "C2"])
-def test_walk_with_a_limit_per_ray(oracle, hip, name, wide, monkeypatch):
+def test_walk_with_a_limit_per_ray(oracle, hip_debug, name, wide, monkeypatch):
     """k_trace on raw rays, each with a limit: NaN (never: the reference's walk), INF (any recorded hit), a distance - with
     binary units and with wide ones (JADE_WIDE: four grandchildren per visit; by default only for trees outside the L2)."""
+    hip = hip_debug
     monkeypatch.setenv("JADE_WIDE", wide)
     hs, _ = config_scene(name)
     n = 40000
@@ -134,8 +136,11 @@ def test_statue_closeup_frames_are_the_same_bits(oracle, hip, wide, monkeypatch)
     with hip.scene(hs) as sh, oracle.scene(hs) as so:
         ref = sh.render(p)
         early = sh.render(q)
+        cached = assert_cached_walk_equals_reference_walk(sh, p, ref)  # ... and with the occluder cache, cold then warm
         r_o, b_o, st_o = so.render(q)  # (the oracle ignores .walk)
     assert_early_exit_equals_reference_walk(ref, early)
+    assert cached[2].rays_cached > 0.2 * (cached[2].rays_shadow + cached[2].rays_env)  # (warm: the second render of the pair)
+    assert cached[2].nodes_visited < early[2].nodes_visited
     assert counters(ref[2]) == counters(st_o)
     assert rel_l2(early[0], r_o) <= 1e-4
     assert early[2].nodes_visited < 0.92 * ref[2].nodes_visited and early[2].tris_tested < 0.88 * ref[2].tris_tested
@@ -158,7 +163,15 @@ def test_progressive_steps_with_early_exits(hip):
             sc.step(spp, st)
         sc.flush(st)
         rgb, bgr = sc.resolve()
+        q.walk = _abi.WALK_EARLY_EXIT_CACHED  # ... and the same steps with the occluder cache
+        sc.begin(q)
+        st_c = _abi.Stats()
+        for spp in (16, 8, 24):
+            sc.step(spp, st_c)
+        sc.flush(st_c)
+        rgb_c, bgr_c = sc.resolve()
     assert_early_exit_equals_reference_walk(ref, (rgb, bgr, st))
+    assert_early_exit_equals_reference_walk(ref, (rgb_c, bgr_c, st_c), fewer=False)
 
 
 def test_unknown_walk_is_refused(hip):
@@ -187,11 +200,12 @@ def _twin_scene(twin_light=False):
     return b.build(), cfg
 
 
-def test_wide_walk_ties_are_walked_again_in_the_references_order(oracle, hip, monkeypatch):
+def test_wide_walk_ties_are_walked_again_in_the_references_order(oracle, hip_debug, monkeypatch):
     """With early exits k_trace walks four grandchildren per visit (jade_trace.h, "Wide walk") - an order of leaves that is not
     the reference's, which only hitArray's tie rule can see (strict "<": of two equal distances the one met first wins,
     PathTrace.cu:787).  A ray for whose best distance two leaves tie is walked again with binary units; on twin geometry that is
     nearly every ray, and index, distance and hit point must be the oracle's for every one of them."""
+    hip = hip_debug
     monkeypatch.setenv("JADE_WIDE", "1")  # (by default only trees that do not fit the L2 get wide records)
     hs, _ = _twin_scene()
     rng = np.random.default_rng(77)
@@ -228,6 +242,92 @@ def test_twin_geometry_frames_are_the_same_bits(oracle, hip, twin_light, wide, m
     with hip.scene(hs) as sh, oracle.scene(hs) as so:
         ref = sh.render(p)
         early = sh.render(q)
+        assert_cached_walk_equals_reference_walk(sh, p, ref, renders=3)
         r_o, b_o, st_o = so.render(p)
     assert counters(ref[2]) == counters(st_o) and rel_l2(ref[0], r_o) <= 1e-4
     assert_early_exit_equals_reference_walk(ref, early, fewer=False)  # (a ray with a tie is walked twice by the wide form)
+
+
+@pytest.mark.parametrize("wide", ["0", "1"])
+@pytest.mark.parametrize("name", ["tinyjade", "C2"])
+def test_cached_walk_answers_every_query_as_the_whole_walk_does(oracle, hip_debug, name, wide, monkeypatch):
+    """The occluder cache on raw rays (jade_trace.h, "Occluder cache"): each ray leaves a source triangle with a limit - NaN: the
+    nearest hit is wanted and the cache must not touch it; INF or a distance: a yes/no query, keyed by its source triangle.  The
+    same batch is traced five times on one scene handle, so that later rounds start from the subtrees earlier rounds cached.  What
+    must hold every time: a query says "yes" (a recorded hit below the limit) exactly when the reference's nearest hit is below the
+    limit, and then reports a hit below the limit that is not nearer than the reference's; otherwise index, distance and hit
+    point are the reference's bits."""
+    monkeypatch.setenv("JADE_WIDE", wide)
+    hip = hip_debug
+    hs, _ = config_scene(name)
+    n = 40000
+    o, d, skip, _ = _aimed_rays(hs, n, 21)
+    rng = np.random.default_rng(8)
+    # every ray leaves a triangle (the key), few distinct sources so that keys repeat
+    v = hs.vertices()
+    src = rng.integers(0, min(hs.n_triangles, 600), n).astype(np.int32)
+    o = np.ascontiguousarray(v[src].mean(1).astype(np.float32))
+    d[1::3] = rng.normal(size=(len(d[1::3]), 3)).astype(np.float32)
+    d = np.ascontiguousarray(d)
+    skip = src
+    with hip.scene(hs) as sh:
+        flags = hip.lib.jade_debug_scene_flags(sh._h)
+        assert flags & 1 and flags & 4, "the scene should have nested boxes and an occluder cache"
+        i0, t0, p0, st0 = sh.trace_rays(o, d, skip)
+        hitm = i0 >= 0
+        assert hitm.sum() > 5000
+        limit = np.full(n, np.float32(np.nan))
+        limit.view(np.int32)[:] = -1
+        kind = rng.integers(0, 4, n)
+        limit[kind == 1] = INF
+        near = np.where(hitm, t0, 1.0).astype(np.float32)
+        limit[kind == 2] = (near * rng.uniform(0.5, 1.0, n).astype(np.float32))[kind == 2]
+        limit[kind == 3] = (near * rng.uniform(1.0, 3.0, n).astype(np.float32))[kind == 3]
+        ends = hitm & (t0 < limit)
+        same = ~ends
+        answered = []
+        for rnd in range(5):
+            i1, t1, p1, st1 = _trace_limit(hip, sh, o, d, skip, limit, cached=True)
+            assert np.array_equal(i1[same], i0[same]) and np.array_equal(t1[same].view(np.uint32), t0[same].view(np.uint32)), rnd
+            assert np.array_equal(p1[same & hitm].view(np.uint32), p0[same & hitm].view(np.uint32)), rnd
+            assert (i1[ends] >= 0).all() and (t1[ends] < limit[ends]).all() and (t1[ends] >= t0[ends]).all(), rnd
+            assert (i1[ends] != skip[ends]).all()
+            answered.append(int(st1.rays_cached))
+    assert ends.sum() > 5000
+    assert answered[0] <= answered[-1] and answered[-1] > 0.3 * ends.sum(), answered  # the cache learns: warm rounds answer more
+    assert answered[-1] <= ends.sum()  # ... and only ever answers "yes" queries
+
+
+def _with_inflated_child_boxes(hs, every, pad):
+    """A copy of the scene whose BVH has every `every`-th non-root node's box padded by `pad` on all sides: still a legal tree for
+    hitBVH (a box only has to contain its triangles), but children now stick out of their parents."""
+    from jaderaytracerendering_amd.host import HostScene
+    arrays = {k: np.array(v, copy=True) for k, v in hs.a.items()}
+    f = arrays["nodes"].view(np.float32)
+    picked = np.arange(2, f.shape[0])[::every]
+    f[picked, 4:7] -= np.float32(pad)
+    f[picked, 7:10] += np.float32(pad)
+    return HostScene(arrays, hs.bvh_depth, 0.0)
+
+
+def test_tree_with_loose_boxes_is_walked_from_the_root_with_binary_units(oracle, hip_debug, monkeypatch):
+    """jade_scene_create takes the caller's BVH.  A legal tree whose child boxes are NOT inside their parents' (padded, refitted) has
+    leaves the reference prunes although their own box is met: neither the wide walk nor the occluder cache may be used on it
+    (ADVICE r3).  Inflate one child box per level of C1's tree: the scene reports "not nested", gets neither wide records nor a
+    cache, and every walk mode still gives the oracle's frame on the same loose tree."""
+    monkeypatch.setenv("JADE_WIDE", "1")
+    hs, cfg = config_scene("C1")
+    loose = _with_inflated_child_boxes(hs, every=3, pad=0.35)
+    p = B.params_from_config(cfg, spp=4)
+    p.width, p.height = 48, 48
+    with hip_debug.scene(loose) as sh, oracle.scene(loose) as so:
+        assert hip_debug.lib.jade_debug_scene_flags(sh._h) == 0
+        ref = sh.render(p)
+        q = type(p).from_buffer_copy(p)
+        q.walk = _abi.WALK_EARLY_EXIT
+        assert_early_exit_equals_reference_walk(ref, sh.render(q))
+        assert_cached_walk_equals_reference_walk(sh, p, ref)
+        r_o, b_o, st_o = so.render(p)
+    assert counters(ref[2]) == counters(st_o) and rel_l2(ref[0], r_o) <= 1e-4
+    with hip_debug.scene(hs) as sh:
+        assert hip_debug.lib.jade_debug_scene_flags(sh._h) == 7  # the tree as built: nested, wide records (JADE_WIDE=1), cache

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _packet_rays(hip, sc, o, d, skip):
-    fn = hip.lib.jade_debug_packet_rays  # development export of libjade_hip.so (not part of jade_rt.h)
+    fn = hip.lib.jade_debug_packet_rays  # libjade_hip_debug.so only (not part of jade_rt.h)
     fn.restype = C.c_int
     fn.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 9
     n = len(o)
@@ -68,12 +68,12 @@ def _rays(hs, packets, seed):
 
 
 @pytest.mark.parametrize("name", ["tiny", "tinyjade", "C2"])
-def test_packet_walk_matches_oracle_ray_by_ray(oracle, hip, name):
+def test_packet_walk_matches_oracle_ray_by_ray(oracle, hip_debug, name):
     hs, _ = config_scene(name)
     o, d, skip = _rays(hs, 42 if name != "C2" else 24, 11)
-    with oracle.scene(hs) as so, hip.scene(hs) as sh:
+    with oracle.scene(hs) as so, hip_debug.scene(hs) as sh:
         want = _oracle_per_ray(so, o, d, skip)
-        got = _packet_rays(hip, sh, o, d, skip)
+        got = _packet_rays(hip_debug, sh, o, d, skip)
     assert np.array_equal(got[0], want[0])
     hit = want[0] >= 0
     assert hit.sum() > 50 and (~hit).sum() > 50
@@ -83,7 +83,7 @@ def test_packet_walk_matches_oracle_ray_by_ray(oracle, hip, name):
     assert np.array_equal(got[4].astype(np.int64), want[4]), "triangle tests per ray"
 
 
-def test_packet_with_a_tie_between_leaves_is_given_up(oracle, hip):
+def test_packet_with_a_tie_between_leaves_is_given_up(oracle, hip_debug):
     """Every triangle of the ball twelve times at the same place, eight triangles to a leaf: every hit on it has twins at exactly
     the same distance in other leaves.  The packet meets leaves in ITS order (left first), a ray's own order is near-first, and hitArray gives a tie
     to the leaf the ray met first (strict "<", PathTrace.cu:787): a packet in which two leaves tie for some ray's best distance
@@ -99,9 +99,9 @@ def test_packet_with_a_tie_between_leaves_is_given_up(oracle, hip):
     hs = b.build()
     o, d, skip = _rays(hs, 60, 3)
     skip[:] = -1
-    with oracle.scene(hs) as so, hip.scene(hs) as sh:
+    with oracle.scene(hs) as so, hip_debug.scene(hs) as sh:
         want = _oracle_per_ray(so, o, d, skip)
-        got = _packet_rays(hip, sh, o, d, skip)
+        got = _packet_rays(hip_debug, sh, o, d, skip)
     assert (want[0] >= 0).sum() > 500
     given_up = (got[0] == -3).reshape(-1, 64)
     assert (given_up.all(1) | ~given_up.any(1)).all(), "a packet is given up as a whole"

@@ -13,7 +13,7 @@ The bar (BASELINE.json north_star / SURVEY.md §8c-d):
 import numpy as np
 import pytest
 
-from conftest import B, J, assert_early_exit_equals_reference_walk, config_scene, counters, rel_l2
+from conftest import assert_cached_walk_equals_reference_walk, B, J, assert_early_exit_equals_reference_walk, config_scene, counters, rel_l2
 from jaderaytracerendering_amd import _abi
 
 pytestmark = pytest.mark.gpu
@@ -37,6 +37,7 @@ def _render_both(oracle, hip, hs, params):
         r_o, b_o, st_o = so.render(params)
         r_h, b_h, st_h = sh.render(params)
         assert_early_exit_equals_reference_walk((r_h, b_h, st_h), sh.render(early))
+        assert_cached_walk_equals_reference_walk(sh, params, (r_h, b_h, st_h))  # ... and with the occluder cache, cold and warm
     # ... and with the wide form of k_trace's walk forced (by default only trees that do not fit the L2 get it)
     import os
     before = os.environ.get("JADE_WIDE")
@@ -44,6 +45,7 @@ def _render_both(oracle, hip, hs, params):
     try:
         with hip.scene(hs) as sw:
             assert_early_exit_equals_reference_walk((r_h, b_h, st_h), sw.render(early))
+            assert_cached_walk_equals_reference_walk(sw, params, (r_h, b_h, st_h))
     finally:
         if before is None:
             del os.environ["JADE_WIDE"]
@@ -232,20 +234,60 @@ def test_result_independent_of_shade_schedule(hip, monkeypatch):
         p = B.params_from_config(cfg, spp=spp)
         p.width, p.height = 40, 36
         ref = None
-        #            split fused batch packet budget wide (k_trace_wide for the walk=1 frame)
-        for v in (("1", "1", "1", "1", "32", "0"), ("1", "1", "1", "0", "32", "1"), ("1", "1", "1", "1", "3", "1"), ("1", "1", "1", "1", "100000", "0"),
-                  ("1", "0", "1", "1", "32", "1"), ("0", "1", "1", "1", "32", "0"), ("1", "1", "0", "1", "32", "1")):
-            for key, val in zip(("JADE_SHADE_SPLIT", "JADE_FUSED", "JADE_BATCH", "JADE_LIGHT_PACKET", "JADE_PACKET_BUDGET", "JADE_WIDE"), v):
+        #            split fused batch packet budget wide (k_trace_wide for the walk=1 frame) tail (k_tail finishes short lists; 0: passes to the end)
+        for v in (("1", "1", "1", "1", "32", "0", "1"), ("1", "1", "1", "0", "32", "1", "0"), ("1", "1", "1", "1", "3", "1", "1"), ("1", "1", "1", "1", "100000", "0", "0"),
+                  ("1", "0", "1", "1", "32", "1", "0"), ("0", "1", "1", "1", "32", "0", "1"), ("1", "1", "0", "1", "32", "1", "0"), ("1", "1", "0", "1", "32", "0", "1"),
+                  ("1", "0", "1", "1", "32", "0", "1")):
+            for key, val in zip(("JADE_SHADE_SPLIT", "JADE_FUSED", "JADE_BATCH", "JADE_LIGHT_PACKET", "JADE_PACKET_BUDGET", "JADE_WIDE", "JADE_TAIL"), v):
                 monkeypatch.setenv(key, val)
             with hip.scene(hs) as sc:
                 rgb, bgr, st = sc.render(p)
                 early = sc.render(_with_walk(p, _abi.WALK_EARLY_EXIT))  # ... and so must the frame with early exits, in every schedule
+                assert_cached_walk_equals_reference_walk(sc, p, (rgb, bgr, st))  # ... and with the occluder cache
             assert_early_exit_equals_reference_walk((rgb, bgr, st), early)
             if ref is None:
                 ref = (rgb, bgr, counters(st))
             else:
                 assert np.array_equal(rgb.view(np.uint32), ref[0].view(np.uint32)) and np.array_equal(bgr, ref[1]), v
                 assert counters(st) == ref[2], v
+
+
+def test_tail_kernel_finishes_what_passes_would(oracle, hip, monkeypatch):
+    """k_tail (round 4): once the active list is short, ONE launch finishes its records - every wave shades and traces its own 64
+    until they are out of samples - instead of a pass per bounce.  Same statements in the same order per record, so the frame,
+    every counter and (reference walk) every node record and triangle test are those of the pass-by-pass schedule and of the
+    oracle; progressive steps with carry-over and a flush included, and a threshold small enough that passes run first."""
+    hs, cfg = config_scene("tinyjade")
+    p = B.params_from_config(cfg, spp=40)
+    p.width, p.height = 72, 56
+    outs = {}
+    for tail, tmax in (("0", "32768"), ("1", "32768"), ("1", "600"), ("1", "64")):
+        monkeypatch.setenv("JADE_TAIL", tail)
+        monkeypatch.setenv("JADE_TAIL_MAX", tmax)
+        with hip.scene(hs) as sc:
+            whole = sc.render(p)
+            sc.begin(p)
+            st = _abi.Stats()
+            for spp in (16, 8, 16):
+                sc.step(spp, st)
+            sc.flush(st)
+            steps = sc.resolve() + (st,)
+            early = sc.render(_with_walk(p, _abi.WALK_EARLY_EXIT))
+        assert_early_exit_equals_reference_walk(whole, early)
+        assert np.array_equal(whole[0].view(np.uint32), steps[0].view(np.uint32)) and counters(whole[2]) == counters(steps[2])
+        outs[(tail, tmax)] = whole
+        if tail == "0":
+            assert whole[2].tail_launches == 0 and whole[2].rays_tail == 0
+        else:
+            assert whole[2].tail_launches >= 1 and 0 < whole[2].rays_tail < whole[2].rays and whole[2].nodes_tail < whole[2].nodes_visited
+    ref = outs[("0", "32768")]
+    for k, o in outs.items():
+        assert np.array_equal(o[0].view(np.uint32), ref[0].view(np.uint32)) and np.array_equal(o[1], ref[1]), k
+        assert counters(o[2]) == counters(ref[2]), k
+    assert outs[("1", "64")][2].trace_launches > outs[("1", "32768")][2].trace_launches  # (a low threshold: passes first)
+    with oracle.scene(hs) as so:
+        r_o, b_o, st_o = so.render(p)
+    assert counters(ref[2]) == counters(st_o) and rel_l2(ref[0], r_o) <= TOL
 
 
 def test_result_independent_of_ray_ordering(hip, monkeypatch):
@@ -263,6 +305,7 @@ def test_result_independent_of_ray_ordering(hip, monkeypatch):
             with hip.scene(hs) as sc:
                 rgb, bgr, st = sc.render(p)
                 early = sc.render(_with_walk(p, _abi.WALK_EARLY_EXIT))
+                assert_cached_walk_equals_reference_walk(sc, p, (rgb, bgr, st))
             assert_early_exit_equals_reference_walk((rgb, bgr, st), early)
             if ref is None:
                 ref = (rgb, bgr, counters(st))
@@ -422,6 +465,20 @@ def test_refraction_material(oracle, hip):
     p = B.params_from_config(cfg, spp=8)
     p.width = p.height = 48
     _assert_parity(*_render_both(oracle, hip, hs, p))
+
+
+def test_glass_statue_config_matches_oracle(oracle, hip):
+    """Config C3G (bench.py's `glass_statue` extra): C3's 69,634-triangle scene with the statue made of DIR_REFRACT glass, the
+    camera moved in so that the serial chain of internal reflections / refractions (PathTrace.cu:1202-1262) is most of the
+    frame's work; the chain must be there (more refraction rays than samples) and everything equal to the oracle."""
+    hs, cfg = config_scene("C3G")
+    centre = hs.vertices()[hs.tri_i32()[:, 0] == 0].reshape(-1, 3).mean(0)
+    eye = [float(x) for x in centre - 0.22 * (-np.array(cfg.camera[8:11], np.float32))]
+    p = B.make_params(80, 48, 6, eye, list(cfg.camera))
+    o, h = _render_both(oracle, hip, hs, p)
+    _assert_parity(o, h)
+    st = h[2]
+    assert st.rays_refract > st.samples and st.rays_shadow == 0 and st.rays_env == 0
 
 
 def test_full_size_properties(hip):

@@ -219,3 +219,27 @@ def test_oracle_tile_filter_renders_exactly_the_listed_tiles(oracle):
     tot = {k: counters(st_a)[k] + counters(st_b)[k] for k in counters(st_a)}
     assert tot == counters(st_full) == counters(st_c)
     assert np.array_equal(c.view(np.uint32), full.view(np.uint32))
+
+
+def test_oracle_tile_filter_change_ends_the_render_in_progress(oracle):
+    """A filter set (or cleared) between jade_render_begin and a step: the sums were laid out for the old filter, so the render is
+    over - step / resolve ask for a new begin instead of indexing the compact sums with -1."""
+    from conftest import config_scene, oracle_tile_filter
+    hs, cfg = config_scene("tinyjade")
+    p = B.params_from_config(cfg, spp=2)
+    p.width, p.height = 40, 40
+    with oracle.scene(hs) as so:
+        so.begin(p)
+        so.step(1)
+        oracle_tile_filter(so, [1, 2])
+        with pytest.raises(B.JadeError):
+            so.step(1)
+        with pytest.raises(B.JadeError):
+            so.resolve()
+        so.begin(p)          # a new render under the new filter works
+        so.step(1)
+        oracle_tile_filter(so, [])
+        with pytest.raises(B.JadeError):
+            so.step(1)
+        rgb, _, _ = so.render(p)
+    assert np.isfinite(rgb).all()

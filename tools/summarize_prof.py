@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Reduces the rocprofv3 CSVs written by tools/profile_r03.sh and cuts the tracked summaries from them.
+"""Reduces the rocprofv3 CSVs written by tools/profile_set.sh and cuts the tracked summaries from them.
 
   summarize_prof.py <tag> --reduce-only   on the GPU box: gpurun_out/<tag>/**.csv -> gpurun_out/<tag>/reduced.json
                                           (per kernel: dispatches, total ns, counter sums; the big per-dispatch CSVs
@@ -25,7 +25,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 O = os.path.join(ROOT, "gpurun_out", tag)
-KERNELS = ("k_trace", "k_light", "k_light_packet", "k_shade", "k_shade_lean", "k_arm", "k_resolve", "k_init", "k_heavy_scan", "k_heavy_pack")
+KERNELS = ("k_trace", "k_tail", "k_light", "k_light_packet", "k_shade", "k_shade_lean", "k_arm", "k_resolve", "k_init", "k_heavy_scan", "k_heavy_pack")
 GATHER_FETCH_FACTOR = 1.0  # profiles/fetch_calibration.json: FETCH_SIZE counts the 64-B sectors a gather moves exactly
 N_CU, N_SIMD = 256, 1024
 VALU_PEAK_LANE_OPS = N_SIMD * 32 * 2.4e9  # one wave64 VALU instruction per SIMD per 2 clocks (bench.py, VALU_PEAK_TLANEOPS)
