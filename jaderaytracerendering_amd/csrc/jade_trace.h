@@ -448,6 +448,9 @@ static __device__ __forceinline__ uint32_t node_core(uint32_t& cur_io, uint32_t&
 // binary units only (JADE_LIMIT_TIE, JADE_FORCE_BINARY: k_trace); rays with a non-finite 1/d take the binary general unit as ever.
 // A leaf chosen as the next node is queued by the following unit (as a leaf that comes off the stack is).
 // ---------------------------------------------------------------------------------------------------------------
+#ifndef JADE_WIDE_ORDERED
+#define JADE_WIDE_ORDERED 0 /* 1: round 3's form - the nearest of the four boxes met is next, the others are pushed nearest last (43 selects per unit).  Round 4, same process (profiles/r04_wide_unordered_ab.txt), k_trace per step: C5 114.8 -> 108.2 ms with the boxes taken in slot order; C3 with JADE_WIDE=1 119.8 -> 114.8 (binary units: 117.9), close-up 832 -> 813 (binary: 809) */
+#endif
 struct NodeRec4 {
   float4 a0, b0, c0, a1, b1, c1;
   uint4 rf;
@@ -495,6 +498,7 @@ static __device__ __forceinline__ uint32_t node_decide4(const NodeRec4& nr, uint
   const bool v1 = rf.y != JADE_REF_NONE, v3 = rf.w != JADE_REF_NONE;  // (slots 0 and 2 always hold a child)
   vcnt += is_leaf ? 0u : 2u + (v1 ? 1u : 0u) + (v3 ? 1u : 0u);
   const bool in0 = !is_leaf && d0 > 0, in1 = !is_leaf && v1 && d1 > 0, in2 = !is_leaf && d2 > 0, in3 = !is_leaf && v3 && d3 > 0;
+#if JADE_WIDE_ORDERED
   // the nearest of the boxes met is next; of the others, the pair it does not belong to goes onto the stack first (it comes off
   // last), its sibling last
   // (decisions as and / or of lane masks: a `?:` between two of them is materialised in a register and compared again)
@@ -509,6 +513,16 @@ static __device__ __forceinline__ uint32_t node_decide4(const NodeRec4& nr, uint
   // pushes, in this order: other pair's farther, other pair's nearer, own pair's farther (in plain slot order instead: the same speed)
   const uint32_t q0 = p1 ? f01 : f23, q1 = p1 ? n01 : n23, q2 = p1 ? f23 : f01;
   const bool w0 = (p1 & fin01) | (!p1 & fin23), w1 = (p1 & nin01) | (!p1 & nin23), w2 = (p1 & fin23) | (!p1 & fin01);
+#else
+  // Unordered (round 4): the boxes met are walked in SLOT order - the first one met is next, the others go onto the stack so that
+  // they come off in slot order.  The order of a wide walk is nobody's business: a ray that wants its nearest hit visits every
+  // box it meets whatever the order (nothing is pruned by distance), a tie between leaves is walked again with binary units
+  // (JADE_LIMIT_TIE), and a yes/no query only ends sooner or later.  What the nearest-first order cost was 43 selects per unit.
+  const bool any = in0 | in1 | in2 | in3;
+  const uint32_t next = in0 ? rf.x : in1 ? rf.y : in2 ? rf.z : rf.w;
+  const uint32_t q0 = rf.w, q1 = rf.z, q2 = rf.y;
+  const bool w0 = in3 & (in0 | in1 | in2), w1 = in2 & (in0 | in1), w2 = in1 & in0;
+#endif
   const uint32_t dummy = stk.col + W_DUMMY * JADE_COL_STRIDE;
   const uint32_t lds_end = stk.col + JADE_LDS_STACK * JADE_COL_STRIDE;
   uint32_t sp = sp_io;

@@ -3,7 +3,8 @@
 statue filling the frame) with several builds of libjade_hip*.so in ONE process, variants interleaved
 (cdna_hip_programming.md rule 24).  Every variant holds its own path state: the device memory is split between them
 through jade_render_params.max_state_bytes, so the records per pixel are fewer than in a bench run (printed).
-usage: ab_variants.py "" _A _B ...      ("" = libjade_hip.so; a name may end in @0 / @1: jade_render_params.walk, default 1 = early exits)"""
+usage: ab_variants.py "" _A _B ...      ("" = libjade_hip.so; a name may end in @0 / @1 / @2: jade_render_params.walk, default 1 = early exits;
+                                         and in %VAR=VAL,...: environment switches read at jade_scene_create, e.g. "_wu@1%JADE_WIDE=1")"""
 import os
 import sys
 import time
@@ -26,10 +27,21 @@ names = sys.argv[1:] or [""]
 budget = int(float(os.environ.get("AB_STATE_GB", "230")) * 1e9 / len(names))
 scenes = {}
 for name in names:
-    libname, _, walk = name.partition("@")
+    name_, _, envs = name.partition("%")   # "<lib suffix>@<walk>%VAR=VAL,VAR2=VAL": environment switches the module reads at jade_scene_create
+    libname, _, walk = name_.partition("@")
     be = B.Backend(os.path.join(ROOT, "jaderaytracerendering_amd", "lib", "libjade_hip%s.so" % libname))
+    saved = {}
+    for kv in filter(None, envs.split(",")):
+        k, _, v = kv.partition("=")
+        saved[k] = os.environ.get(k)
+        os.environ[k] = v
     sc = be.scene(hs)
-    p = B.make_params(W, H, 1024, eye, list(cfg.camera), walk=int(walk or 1))
+    for k, v in saved.items():
+        if v is None:
+            del os.environ[k]
+        else:
+            os.environ[k] = v
+    p = B.make_params(W, H, SPP * (ROUNDS + 1), eye, list(cfg.camera), walk=int(walk or 1))  # (announced = what will be rendered: the partial sums are sized by it)
     p.max_state_bytes = budget
     sc.begin(p)
     sc.step(SPP)
@@ -42,9 +54,9 @@ for rnd in range(ROUNDS):
         t = time.perf_counter()
         sc.step(SPP, st)
         dt = time.perf_counter() - t
-        rays_t = st.rays - st.rays_inline
+        rays_t = st.rays - st.rays_inline - st.rays_tail
         r = (st.rays / dt / 1e6, st.trace_ms, st.light_ms, st.kernel_ms, rays_t / max(st.trace_ms, 1e-9) / 1e3,
-             (st.nodes_visited - st.nodes_inline) / max(rays_t, 1), (st.tris_tested - st.tris_inline) / max(rays_t, 1))
+             (st.nodes_visited - st.nodes_inline - st.nodes_tail) / max(rays_t, 1), (st.tris_tested - st.tris_inline - st.tris_tail) / max(rays_t, 1))
         if name not in best or r[0] > best[name][0]:
             best[name] = r
 for name, r in best.items():
