@@ -50,6 +50,10 @@ def _ranks(cmd, extra_env=None):
     env["JADE_BENCH_PLUMBING_ONLY"] = "1"
     env.update(extra_env or {})
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    if out.returncode != 0 and "--master-port" in cmd:  # (a port found free a moment ago may have been taken since: once more, on another)
+        cmd = list(cmd)
+        cmd[cmd.index("--master-port") + 1] = str(_free_port())
+        out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     recs = [json.loads(line) for line in out.stdout.splitlines() if line.startswith("{")]
     return sorted(recs, key=lambda r: r["rank"])
