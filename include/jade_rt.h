@@ -160,8 +160,17 @@ typedef struct jade_render_params {
    * zero-filled struct asks for) visits what the reference visits: nodes_visited / tris_tested equal the oracle's.
    * Oracle: ignored (it is the reference walk). */
   int32_t walk;
-  int32_t reserved0;     /* 0 */
+  /* How the direction of an environment-visibility ray is drawn - JADE_ENV_*.  JADE_ENV_REFERENCE (0, what a zero-filled struct asks
+   * for): uniformly over the hemisphere, as the reference does (PathTrace.cu:968-979, 1111-1122, 1304-1315) - the mode every parity
+   * statement of this header is about.  JADE_ENV_IMPORTANCE (ABI 7; SURVEY 8f rank 3, "optional importance sampling (non-parity
+   * mode)"): proportionally to the environment map's luminance x sin(theta) per texel, weighted by 1 / pdf (a direction on the wrong
+   * side of the surface contributes nothing and no ray is traced for it).  A different estimator of the SAME integral: the image
+   * converges to the same mean with less noise under a sky with a sun, and is NOT the reference's sample for sample - none of the
+   * parity claims apply to it, and the oracle refuses it (JADE_ERR_UNSUPPORTED). */
+  int32_t env_sampling;
 } jade_render_params;
+#define JADE_ENV_REFERENCE 0
+#define JADE_ENV_IMPORTANCE 1
 #define JADE_WALK_REFERENCE 0
 #define JADE_WALK_EARLY_EXIT 1
 /* JADE_WALK_EARLY_EXIT plus an occluder cache (ABI 7).  The reference tests a leaf's triangles iff the ray meets the leaf's box

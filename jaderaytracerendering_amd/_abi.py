@@ -15,6 +15,7 @@ TILE_SIZE = 16
 TONEMAP_ACES, TONEMAP_REINHARD = 0, 1
 Q_RECORDS_PER_PIXEL, Q_STATE_BYTES, Q_SUM_LANES = 0, 1, 2
 WALK_REFERENCE, WALK_EARLY_EXIT, WALK_EARLY_EXIT_CACHED = 0, 1, 2
+ENV_REFERENCE, ENV_IMPORTANCE = 0, 1
 
 f3 = C.c_float * 3
 f16 = C.c_float * 16
@@ -62,7 +63,7 @@ class RenderParams(C.Structure):
         ("device_id", C.c_int32), ("threads", C.c_int32),
         ("max_state_bytes", C.c_uint64),
         ("walk", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("env_sampling", C.c_int32),
     ]
 
 

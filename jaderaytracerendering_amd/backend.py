@@ -22,14 +22,15 @@ class JadeError(RuntimeError):
         self.code = code
 
 
-def make_params(width, height, spp, eye, camera, frame=0, tile_rank=0, tile_nranks=1, device_id=0, threads=0, walk=_abi.WALK_REFERENCE):
+def make_params(width, height, spp, eye, camera, frame=0, tile_rank=0, tile_nranks=1, device_id=0, threads=0, walk=_abi.WALK_REFERENCE, env_sampling=_abi.ENV_REFERENCE):
     p = _abi.RenderParams()
     p.width, p.height, p.spp, p.frame = int(width), int(height), int(spp), int(frame)
     p.eye[:] = [float(v) for v in eye]
     p.camera[:] = [float(v) for v in camera]
     p.tile_rank, p.tile_nranks = int(tile_rank), int(tile_nranks)
     p.device_id, p.threads = int(device_id), int(threads)
-    p.walk = int(walk)  # jade_rt.h, JADE_WALK_*: 0 = the reference's walk (V / T equal the oracle's), 1 = early exits
+    p.walk = int(walk)  # jade_rt.h, JADE_WALK_*: 0 = the reference's walk (V / T equal the oracle's), 1 = early exits, 2 = + occluder cache
+    p.env_sampling = int(env_sampling)  # JADE_ENV_*: 0 = the reference's estimator; 1 = environment rays by importance (non-parity)
     return p
 
 

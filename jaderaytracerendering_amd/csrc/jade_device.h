@@ -114,6 +114,10 @@ struct DevScene {
   // the tree does not allow it (boxes not nested, a missing child, too deep).  The one piece of the scene the kernels WRITE: hints
   // only, a stale or torn entry costs a walk and never an answer.
   uint4* anyhit;
+  // Environment importance sampling (jade_render_params.env_sampling, non-parity): an alias table over the map's texels, weight =
+  // (luminance + a floor) x sin(theta of the row); per texel {acceptance threshold, alias texel, this texel's pdf x W x H, the
+  // alias texel's} - one 16-B gather per draw (jade_shade.h, env_sample)
+  const uint4* env_alias;
 };
 
 // Path records, structure of arrays.  Samples are independent work items
@@ -173,6 +177,7 @@ struct PathState {
   // hit is wanted; JADE_INF_F = any recorded hit (hitArray records a hit only below INF, PathTrace.cu:787); a shadow ray carries
   // the distance at which hitTriangle meets the emitter it aims at (JADE_INF_F if it does not: then no hit can make it
   // visible).  -2 (also a NaN) = no ray in this slot.  With the reference walk k_trace ignores the word.
+  uint32_t env_sampling;  // JADE_ENV_*: 1 = environment rays drawn by importance (non-parity mode)
   uint32_t early_exit;  // 0: the reference's walk; 1: early exits; 2: early exits + the occluder cache (JADE_WALK_EARLY_EXIT_CACHED)
 };
 
@@ -190,6 +195,7 @@ enum : uint32_t {
 #define STF_SSS 1u      /* ST_DIFFUSE: SSS-diffuse variant (albedo, x4) */
 #define STF_RR 2u       /* the indirect ray was issued (RR passed) */
 #define STF_FULLREFLEX 4u
+#define STF_NOENV 8u    /* ST_DIFFUSE / ST_BSSRDF with env_sampling: the drawn direction lay on the wrong side - no environment ray this bounce */
 
 struct RenderConst {
   int32_t width, height;

@@ -31,6 +31,7 @@
 #include <rccl/rccl.h>  // types only: the library is loaded on first use (jade_render_multi on distinct devices)
 
 #include <algorithm>
+#include <cmath>
 #include <map>
 #include <thread>
 #include <cstdio>
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(JADE_ARM_BLOCK) void k_arm(PathState P, uint32_t ta
 // the sky and pure mirrors: it hands every other record to the full kernel through `defer`
 // (either untouched, or parked at ST_VERTEX with its path state stored).  Same statements either
 // way: the lean paths are the shared helpers consume_mirror / begin_bounce_lean / bounce_mirror.
-template <bool LEAN>
+template <bool LEAN, bool ENVIS = false>  // ENVIS: environment rays by importance (non-parity; k_shade_envis only)
 static __device__ __forceinline__ void shade_record(const DevScene& S, const PathState& P, const RenderConst& R, const int32_t* tile_ids,
                                                     uint32_t target_spp, const int p, ShadeCtx& c, uint32_t& st_out, bool& defer) {
   const int npix = P.npix;
@@ -273,7 +274,7 @@ static __device__ __forceinline__ void shade_record(const DevScene& S, const Pat
         st = ST_VERTEX;
       }
     } else if (on_path) {
-      int r = LEAN ? consume_mirror(S, px, c, &l_final) : consume(S, px, c, &l_final);
+      int r = LEAN ? consume_mirror(S, px, c, &l_final) : consume<ENVIS>(S, px, c, &l_final);
       if (r == CONSUME_VERTEX) {
         st = ST_VERTEX;
       } else if (r == CONSUME_EMITTED) {
@@ -305,9 +306,20 @@ static __device__ __forceinline__ void shade_record(const DevScene& S, const Pat
           defer = true;
           break;
         }
-        if (LEAN ? begin_bounce_lean(S, px, c, &l_final) : begin_bounce(S, px, c, &l_final)) {
+        if (LEAN ? begin_bounce_lean(S, px, c, &l_final) : begin_bounce<ENVIS>(S, px, c, &l_final)) {
           st = c.stage;
-          break;
+          if (!ENVIS || c.n_emit_rays != 0) break;
+          // env_sampling only: a bounce that emitted NO ray (the drawn sky direction lay on the wrong side, no shadow ray faced its
+          // emitter, the roulette ended the path) has all its results already - nothing is visible: folded in right here (with the
+          // reference's sampling there is always the environment ray)
+          const int r = consume<ENVIS>(S, px, c, &l_final);
+          if (r == CONSUME_VERTEX) {
+            st = ST_VERTEX;
+            continue;
+          }
+          color = r == CONSUME_END ? jv_add(c.le, jv_add(c.acc, jv_mul(c.thr, l_final))) : c.le;
+          finished = true;
+          continue;
         }
         color = jv_add(c.le, jv_add(c.acc, jv_mul(c.thr, l_final)));
         finished = true;
@@ -344,8 +356,9 @@ static __device__ __forceinline__ void shade_record(const DevScene& S, const Pat
     if (st != ST_PRIMARY && c.n_emit_rays) {  // the secondary rays of this pass by hitBVH call site (jade_rt.h)
       if (st == ST_DIFFUSE || st == ST_BSSRDF) {
         const uint32_t ind = (c.flags & STF_RR) ? 1u : 0u;
-        c.c_cls += 1u | (ind << 8);  // one environment ray always, the indirect ray if the roulette passed
-        c.c_shadow += (uint32_t)c.n_emit_rays - 1u - ind;
+        const uint32_t env = (c.flags & STF_NOENV) ? 0u : 1u;  // one environment ray always (env_sampling: unless its direction lay on the wrong side)
+        c.c_cls += env | (ind << 8);  // ... and the indirect ray if the roulette passed
+        c.c_shadow += (uint32_t)c.n_emit_rays - env - ind;
       } else {
         c.c_cls += st == ST_MIRROR ? (1u << 16) : (1u << 24);
       }
@@ -452,7 +465,8 @@ static __device__ __forceinline__ void shade_tail(const PathState& P, int p, uin
 
 // The full shade kernel: one thread per entry of `list` (the active list, or — after k_shade_lean —
 // the records that kernel handed over, whose count lives on the device: n_dev).  75 VGPRs, 6 waves/SIMD (JADE_SHADE_WAVES).
-__global__ __launch_bounds__(JADE_SHADE_BLOCK, JADE_SHADE_WAVES) void k_shade(DevScene S, PathState P, RenderConst R, const int32_t* tile_ids,
+template <bool ENVIS>
+static __device__ __forceinline__ void shade_kernel_body(const DevScene& S, const PathState& P, const RenderConst& R, const int32_t* tile_ids,
                                                uint32_t target_spp, const uint32_t* list, uint32_t n_host, const uint32_t* n_dev,
                                                uint32_t* active_out, uint32_t* queue, QueueCtl* qc, DevCounters* ctr, const QueueCtl* prev,
                                                uint32_t stop_below) {
@@ -473,7 +487,290 @@ __global__ __launch_bounds__(JADE_SHADE_BLOCK, JADE_SHADE_WAVES) void k_shade(De
   c.c_primary = c.c_shadow = c.c_shaded = c.c_samples = c.c_cls = 0;
   uint32_t st;
   bool defer;
-  shade_record<false>(S, P, R, tile_ids, target_spp, p, c, st, defer);
+  shade_record<false, ENVIS>(S, P, R, tile_ids, target_spp, p, c, st, defer);
+  shade_tail<false, JADE_SHADE_NW>(P, p, st, c, false, active_out, nullptr, queue, qc, ctr);
+}
+__global__ __launch_bounds__(JADE_SHADE_BLOCK, JADE_SHADE_WAVES) void k_shade(DevScene S, PathState P, RenderConst R, const int32_t* tile_ids,
+                                               uint32_t target_spp, const uint32_t* list, uint32_t n_host, const uint32_t* n_dev,
+                                               uint32_t* active_out, uint32_t* queue, QueueCtl* qc, DevCounters* ctr, const QueueCtl* prev,
+                                               uint32_t stop_below) {
+  shade_kernel_body<false>(S, P, R, tile_ids, target_spp, list, n_host, n_dev, active_out, queue, qc, ctr, prev, stop_below);
+}
+// ... with jade_render_params.env_sampling = JADE_ENV_IMPORTANCE (non-parity): the one kernel that carries that code
+__global__ __launch_bounds__(JADE_SHADE_BLOCK, JADE_SHADE_WAVES) void k_shade_envis(DevScene S, PathState P, RenderConst R, const int32_t* tile_ids,
+                                               uint32_t target_spp, const uint32_t* list, uint32_t n_host, const uint32_t* n_dev,
+                                               uint32_t* active_out, uint32_t* queue, QueueCtl* qc, DevCounters* ctr, const QueueCtl* prev,
+                                               uint32_t stop_below) {
+  shade_kernel_body<true>(S, P, R, tile_ids, target_spp, list, n_host, n_dev, active_out, queue, qc, ctr, prev, stop_below);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_shade_binned (round 4; VERDICT r1-r3: "k_shade is one divergent kernel at 13 of 64 lanes").  k_shade's instructions are mostly
+// the BRANCH of the bounce it samples - BSSRDF (six powf, the exit-point search), SSS / diffuse (shadow limits, two sphere
+// directions), mirror, refraction - and a wave whose 64 records take four different branches runs all four, each for a quarter of
+// its lanes.  Which branch a record takes is known after the emissive test and one or two random draws (bounce_classify), and the
+// branch itself needs little of the record: its random state, the vertex (triangle, position, outgoing direction) and the
+// record's number, through which it writes its rays.  So the block DEALS the records by branch through LDS: every thread loads
+// and folds its own record as before (shade_record's part (a)), classifies it, and puts those few words into a pool in which
+// every branch's records form a stretch that starts at a multiple of 64; then every thread runs bounce_branch for the pool entry
+// with its own index - a wave's 64 entries are one branch - and writes the outcome back; the record's own thread picks it up,
+// finishes the sample / starts the next one if the path ended, and stores and queues as ever (shade_tail).  Same statements, same
+// draws in the same order per record: every bit and counter is k_shade's (the schedule matrix runs both: JADE_SHADE_BINNED).
+// ---------------------------------------------------------------------------------------------------------------
+#ifndef JADE_SHADE_BIN_WAVES
+#define JADE_SHADE_BIN_WAVES 4 /* 109 VGPRs, no scratch: "rest" of a 1024-spp step of C3 134.6 ms; 5 waves (96 VGPRs, 20 bytes of scratch) 141.8; 6 (80, 128 bytes) 166.7; k_shade: 132.1 */
+#endif
+#define JADE_BIN_POOL (JADE_SHADE_BLOCK + (BT_N - 1) * 64) /* pool entries: 512 records + the padding of four stretches */
+struct alignas(16) BinSlot {  // 48 bytes
+  int32_t p;       // the record
+  uint32_t rng;    // its random state: in = after bounce_classify's draws, out = after the branch's
+  int32_t obj;     // the vertex: triangle ...
+  uint32_t sf;     // in: stage | flags << 8 (BT_DIFFUSE: set by bounce_classify); out: stage | flags << 8 | rays emitted << 16 | path ended << 31
+  float src[3];    // ... position            (out: l_final of a path that ended)
+  float out[3];    // ... outgoing direction
+  float pad[2];
+};
+__global__ __launch_bounds__(JADE_SHADE_BLOCK, JADE_SHADE_BIN_WAVES) void k_shade_binned(DevScene S, PathState P, RenderConst R, const int32_t* tile_ids,
+                                               uint32_t target_spp, const uint32_t* list, uint32_t n_host, const uint32_t* n_dev,
+                                               uint32_t* active_out, uint32_t* queue, QueueCtl* qc, DevCounters* ctr, const QueueCtl* prev,
+                                               uint32_t stop_below) {
+  const uint32_t n = n_dev ? *n_dev : n_host;
+  if (prev && (prev->count == 0 || n < stop_below)) {  // (as k_shade: a pass of a batch behind the end of the step)
+    if (blockIdx.x == 0 && threadIdx.x == 0) qc->active = prev->count == 0 ? 0u : n;
+    return;
+  }
+  if (blockIdx.x * blockDim.x >= n) return;
+  __shared__ BinSlot pool[JADE_BIN_POOL];
+  __shared__ uint32_t sh_cnt[JADE_SHADE_NW][BT_N];
+  __shared__ uint32_t sh_base[BT_N], sh_n[BT_N];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const uint32_t t_idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int npix = P.npix;
+  const int p = t_idx < n ? (int)list[t_idx] : npix;
+  ShadeCtx c;
+  c.n_emit_rays = 0;
+  c.c_primary = c.c_shadow = c.c_shaded = c.c_samples = c.c_cls = 0;
+  // ---- (1) the thread's own record: load, fold in the results of the rays issued last pass (shade_record<false>, prologue + (a))
+  uint32_t st = ST_INVALID;
+  const int pp = p < npix ? p : 0;
+  const uint4 hdr0 = P.hdr[pp];
+  const uint32_t word = hdr0.z;
+  const float4 slot0 = P.slot[(size_t)pp * P.nslots * 2];
+  const int hit0 = __float_as_int(slot0.w);
+  const jvec3 dir0 = jv(slot0.x, slot0.y, slot0.z);
+  const uint32_t rec_m = (uint32_t)pp / (uint32_t)P.npx;
+  const int home_pix = (int)((uint32_t)pp - rec_m * (uint32_t)P.npx);
+  const int tid0 = tile_ids[home_pix >> 8];
+  if (p < npix) st = word & 255u;
+  const bool have = st != ST_INVALID;
+  const Px px(P, pp);
+  uint32_t done = hdr0.y;
+  jvec3 l_final = jv(0, 0, 0), color = jv(0, 0, 0);
+  bool finished = false;
+  int type = -1;  // the branch this record's bounce takes (BT_*), -1 = none this pass
+  if (have) {
+    const bool on_path = st >= ST_DIFFUSE && st <= ST_REFRACT_EXIT;
+    const bool has_ctx = on_path || st == ST_VERTEX;
+    c.rng = hdr0.x;
+    c.depth = (word >> 8) & 255u;
+    c.flags = word >> 16;
+    c.stage = st;
+    c.thr = jv(1, 1, 1);
+    c.acc = jv(0, 0, 0);
+    c.le = jv(0, 0, 0);
+    c.obj = 0;
+    c.src = jv(0, 0, 0);
+    c.out = jv(0, 0, 0);
+    if (has_ctx) {
+      const float4* cx = P.ctx + (size_t)p * 4;
+      const float4 b0 = cx[0], b1 = cx[1], b2 = cx[2], b3 = cx[3];
+      c.obj = __float_as_int(b0.w);
+      if (c.depth != 0) {
+        c.thr = jv(b0.x, b0.y, b0.z);
+        c.acc = jv(b1.x, b1.y, b1.z);
+      }
+      if (st == ST_MIRROR && c.depth == 0) c.le = V3(shade_tri(S, c.obj).m->emissive);
+      else c.le = jv(b2.x, b2.y, b2.z);
+      if (st != ST_MIRROR) {
+        c.src = jv(b2.w, b3.x, b3.y);
+        c.out = jv(b3.z, b3.w, b1.w);
+      }
+    }
+    if (st == ST_PRIMARY) {
+      if (hit0 < 0) {
+        color = sample_hdr(S, dir0);  // PathTrace.cu:1443-1445
+        finished = true;
+      } else {
+        c.le = V3(shade_tri(S, hit0).m->emissive);
+        c.thr = jv(1, 1, 1);
+        c.acc = jv(0, 0, 0);
+        c.depth = 0;
+        c.obj = hit0;
+        c.src = px.hpt(0);
+        c.out = jv_neg(dir0);
+        st = ST_VERTEX;
+      }
+    } else if (on_path) {
+      const int r = consume(S, px, c, &l_final);
+      if (r == CONSUME_VERTEX) {
+        st = ST_VERTEX;
+      } else if (r == CONSUME_EMITTED) {
+        st = c.stage;
+      } else {
+        color = r == CONSUME_END ? jv_add(c.le, jv_add(c.acc, jv_mul(c.thr, l_final))) : c.le;
+        finished = true;
+      }
+    }
+    // ---- (2) the branch of the bounce at a vertex (the emissive test ends the path right here)
+    if (!finished && st == ST_VERTEX) {
+      type = bounce_classify(S, c, &l_final);
+      if (type == BT_END) {
+        color = jv_add(c.le, jv_add(c.acc, jv_mul(c.thr, l_final)));
+        finished = true;
+        type = -1;
+      }
+    }
+  }
+  // ---- (3) deal: every branch's records into a stretch of the pool that starts at a multiple of 64
+  uint32_t rank = 0;
+#pragma unroll
+  for (int T = 1; T < BT_N; ++T) {
+    const unsigned long long m = __ballot(type == T);
+    if (type == T) rank = (uint32_t)__popcll(m & below);
+    if (lane == 0) sh_cnt[w][T] = (uint32_t)__popcll(m);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t base = 0;
+    for (int T = 1; T < BT_N; ++T) {
+      uint32_t tot = 0;
+      for (int i = 0; i < JADE_SHADE_NW; ++i) {
+        const uint32_t v = sh_cnt[i][T];
+        sh_cnt[i][T] = tot;  // exclusive over the waves
+        tot += v;
+      }
+      sh_base[T] = base;
+      sh_n[T] = tot;
+      base += (tot + 63u) & ~63u;
+    }
+    sh_base[0] = base;  // the end of the pool
+  }
+  __syncthreads();
+  uint32_t my_entry = 0;
+  if (type >= 1) {
+    my_entry = sh_base[type] + sh_cnt[w][type] + rank;
+    BinSlot& e = pool[my_entry];
+    e.p = p;
+    e.rng = c.rng;
+    e.obj = c.obj;
+    e.sf = c.stage | (c.flags << 8);
+    e.src[0] = c.src.x; e.src[1] = c.src.y; e.src[2] = c.src.z;
+    e.out[0] = c.out.x; e.out[1] = c.out.y; e.out[2] = c.out.z;
+  }
+  __syncthreads();
+  // ---- (4) the branch, for the pool entry with this thread's index: one branch per wave
+  {
+    const uint32_t pool_end = sh_base[0];
+    for (uint32_t ei = threadIdx.x; ei < pool_end; ei += JADE_SHADE_BLOCK) {  // (a second turn only when the padding pushes the pool past the block)
+      int T = 0;
+#pragma unroll
+      for (int k = 1; k < BT_N; ++k)
+        if (ei >= sh_base[k] && ei < sh_base[k] + sh_n[k]) T = k;
+      if (T != 0) {
+        BinSlot& e = pool[ei];
+        ShadeCtx wc;
+        wc.rng = e.rng;
+        wc.obj = e.obj;
+        wc.stage = e.sf & 255u;
+        wc.flags = (e.sf >> 8) & 255u;
+        wc.depth = 0;
+        wc.src = jv(e.src[0], e.src[1], e.src[2]);
+        wc.out = jv(e.out[0], e.out[1], e.out[2]);
+        wc.thr = wc.acc = wc.le = jv(0, 0, 0);
+        wc.n_emit_rays = 0;
+        wc.c_primary = wc.c_shadow = wc.c_shaded = wc.c_samples = wc.c_cls = 0;
+        const Px wpx(P, e.p);
+        jvec3 wl = jv(0, 0, 0);
+        const bool emitted = bounce_branch(T, S, wpx, wc, &wl);
+        e.rng = wc.rng;
+        e.sf = (wc.stage & 255u) | ((wc.flags & 255u) << 8) | ((uint32_t)wc.n_emit_rays << 16) | (emitted ? 0u : 0x80000000u);
+        e.src[0] = wl.x; e.src[1] = wl.y; e.src[2] = wl.z;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- (5) back with the record's own thread: the branch's outcome, then shade_record's part (b) for a sample that ended
+  if (type >= 1) {
+    const BinSlot& e = pool[my_entry];
+    c.rng = e.rng;
+    if (e.sf & 0x80000000u) {
+      l_final = jv(e.src[0], e.src[1], e.src[2]);
+      color = jv_add(c.le, jv_add(c.acc, jv_mul(c.thr, l_final)));
+      finished = true;
+    } else {
+      c.stage = e.sf & 255u;
+      c.flags = (e.sf >> 8) & 255u;
+      c.n_emit_rays = (int)((e.sf >> 16) & 0x7fffu);
+      st = c.stage;
+    }
+  }
+  if (have) {
+    if (finished) {
+      // final_result = final_result + color (PathTrace.cu:1454), into the partial sum of this sample's (pixel, lane)
+      const NextSample cs = next_sample_mh(P, rec_m, (uint32_t)home_pix, done);  // the sample that just ended
+      const size_t si = (size_t)(cs.sidx % JADE_SAMPLE_LANES) * (size_t)P.npx + (size_t)cs.pixel;
+      const size_t sn = (size_t)P.sum_lanes * (size_t)P.npx;
+      st3w(P.sum, sn, si, jv_add(ld3w(P.sum, sn, si), color));
+      done += 1;
+      c.c_samples += 1;
+      st = ST_IDLE;
+    }
+    if (st == ST_IDLE) {
+      // next sample of this record; samples of out-of-image pixels (edge tiles) are skipped
+      int x, y;
+      NextSample ns = next_sample_mh(P, rec_m, (uint32_t)home_pix, done);
+      while (ns.sidx < target_spp && !pixel_xy_t(R, ns.pixel == home_pix ? tid0 : tile_ids[ns.pixel >> 8], ns.pixel, &x, &y)) {
+        done += 1;
+        ns = next_sample_mh(P, rec_m, (uint32_t)home_pix, done);
+      }
+      if (ns.sidx < target_spp) {
+        // camera ray, PathTrace.cu:1428-1437
+        c.rng = jade_rng_seed((uint32_t)x, (uint32_t)y, R.frame + ns.sidx);
+        float fx = (float)x + jade_rand(&c.rng);
+        double lo = -1.0 + R.two_over_w * ((double)fx - 0.5);
+        float left_offset = (float)(lo * R.aspect);
+        float fy = (float)y + jade_rand(&c.rng);
+        float up_offset = (float)(-1.0 + R.two_over_h * ((double)fy - 0.5));
+        jvec3 dir = jade_transform(jv(left_offset, up_offset, -1.5f), 0.0f, R.cam);
+        dir = jv_normalize(dir);
+        reinterpret_cast<int*>(P.orgs + p)[3] = JADE_SKIP_CAMERA;
+        px.set_dir(0, dir);
+        px.set_hit(0, -1);
+        c.n_emit_rays = 1;
+        c.c_primary += 1;
+        st = ST_PRIMARY;
+      }
+    }
+    if (st != ST_PRIMARY && c.n_emit_rays) {  // the secondary rays of this pass by hitBVH call site (jade_rt.h)
+      if (st == ST_DIFFUSE || st == ST_BSSRDF) {
+        const uint32_t ind = (c.flags & STF_RR) ? 1u : 0u;
+        const uint32_t env = (c.flags & STF_NOENV) ? 0u : 1u;
+        c.c_cls += env | (ind << 8);
+        c.c_shadow += (uint32_t)c.n_emit_rays - env - ind;
+      } else {
+        c.c_cls += st == ST_MIRROR ? (1u << 16) : (1u << 24);
+      }
+    }
+    P.hdr[p] = make_uint4(c.rng, done, st | (c.depth << 8) | (c.flags << 16), 0u);
+    if ((st >= ST_DIFFUSE && st <= ST_REFRACT_EXIT) || st == ST_VERTEX) {
+      float4* cx = P.ctx + (size_t)p * 4;
+      cx[0] = make_float4(c.thr.x, c.thr.y, c.thr.z, __int_as_float(c.obj));
+      cx[1] = make_float4(c.acc.x, c.acc.y, c.acc.z, c.out.z);
+      cx[2] = make_float4(c.le.x, c.le.y, c.le.z, c.src.x);
+      cx[3] = make_float4(c.src.y, c.src.z, c.out.x, c.out.y);
+    }
+  }
   shade_tail<false, JADE_SHADE_NW>(P, p, st, c, false, active_out, nullptr, queue, qc, ctr);
 }
 
@@ -1588,6 +1885,7 @@ struct Tunables {
   int packet_budget = JADE_PACKET_BUDGET;  // JADE_PACKET_BUDGET: records a packet may read before it is given up and walked per lane
   int wide_mode = -1;         // JADE_WIDE: with early exits k_trace walks four grandchildren per visit (k_trace_wide): 1 always, 0 never, unset =
                               // when the traversal's records do not fit the L2 (the rule of sort_mode; jade_scene_create then builds wide records)
+  bool shade_binned = false;  // JADE_SHADE_BINNED=1: k_shade_binned - the records of a block dealt by branch through LDS (measured level with k_shade: DESIGN.md 3.4)
   bool tail = true;           // JADE_TAIL=0: no k_tail - the last paths are finished by passes, as before round 4
   uint32_t tail_max = JADE_TAIL_MAX;  // JADE_TAIL_MAX: active records at or below which k_tail takes over
   bool anyhit = true;         // JADE_ANYHIT=0: no occluder cache (JADE_WALK_EARLY_EXIT_CACHED then walks as JADE_WALK_EARLY_EXIT)
@@ -1597,6 +1895,7 @@ struct Tunables {
     tail = !flag0("JADE_TAIL");
     if (const char* e = getenv("JADE_TAIL_MAX")) tail_max = (uint32_t)atoi(e);
     auto flag1 = [](const char* n) { const char* e = getenv(n); return e && atoi(e) > 0; };
+    shade_binned = flag1("JADE_SHADE_BINNED");
     shade_split = !flag0("JADE_SHADE_SPLIT");
     fused = shade_split && !flag0("JADE_FUSED");
     batching = !flag0("JADE_BATCH");
@@ -1620,7 +1919,7 @@ struct jade_scene {
   Tunables tun;
   hipStream_t stream = nullptr;
   DevScene dev{};
-  DevBuf b_nodes, b_nodes4, b_tverts, b_tris, b_emit, b_mapping, b_prefix, b_segs, b_env, b_guide, b_guide_obj, b_tnorm, b_mats, b_anyhit;
+  DevBuf b_nodes, b_nodes4, b_tverts, b_tris, b_emit, b_mapping, b_prefix, b_segs, b_env, b_guide, b_guide_obj, b_tnorm, b_mats, b_anyhit, b_env_alias;
   bool boxes_nested = true;   // every child's box lies inside its parent's (jade_scene_create): what the wide walk and the occluder cache need
   int n_emit = 0;
   int bvh_depth = 0;
@@ -2100,6 +2399,58 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
     }
   }
 
+  // Environment importance sampling (jade_render_params.env_sampling; non-parity): Vose's alias table over the texels, weight =
+  // (luminance + 1 % of the mean luminance) x sin(theta of the row's centre) - the floor keeps every texel drawable, so the
+  // estimator stays unbiased wherever the sky is not black
+  std::vector<uint4> env_alias;
+  {
+    const size_t W = (size_t)d->env_width, H = (size_t)d->env_height, N = W * H;
+    std::vector<double> wgt(N);
+    double lum_sum = 0;
+    for (size_t i = 0; i < N; ++i) {
+      const float* t = d->env_rgb + 3 * i;
+      const double l = 0.2126 * std::max(t[0], 0.0f) + 0.7152 * std::max(t[1], 0.0f) + 0.0722 * std::max(t[2], 0.0f);
+      wgt[i] = std::isfinite(l) ? l : 0.0;
+      lum_sum += wgt[i];
+    }
+    const double floor_l = lum_sum > 0 ? 0.01 * lum_sum / (double)N : 1.0;
+    double total = 0;
+    for (size_t j = 0; j < H; ++j) {
+      const double st = std::sin(JADE_PI_D * ((double)j + 0.5) / (double)H);
+      for (size_t i = 0; i < W; ++i) {
+        wgt[j * W + i] = (wgt[j * W + i] + floor_l) * st;
+        total += wgt[j * W + i];
+      }
+    }
+    std::vector<double> q(N);
+    std::vector<uint32_t> small, large, alias(N);
+    std::vector<float> accept(N, 1.0f);
+    for (size_t i = 0; i < N; ++i) {
+      q[i] = wgt[i] / total * (double)N;  // the texel's probability x N (mean 1)
+      alias[i] = (uint32_t)i;
+      (q[i] < 1.0 ? small : large).push_back((uint32_t)i);
+    }
+    std::vector<double> r = q;
+    while (!small.empty() && !large.empty()) {
+      const uint32_t a = small.back(), g = large.back();
+      small.pop_back();
+      accept[a] = (float)r[a];
+      alias[a] = g;
+      r[g] = (r[g] + r[a]) - 1.0;
+      if (r[g] < 1.0) { large.pop_back(); small.push_back(g); }
+    }
+    env_alias.resize(N);
+    for (size_t i = 0; i < N; ++i) {
+      const float ps = (float)q[i], pa = (float)q[alias[i]];
+      uint4 e;
+      memcpy(&e.x, &accept[i], 4);
+      e.y = alias[i];
+      memcpy(&e.z, &ps, 4);
+      memcpy(&e.w, &pa, 4);
+      env_alias[i] = e;
+    }
+  }
+
   jade_scene* s = new (std::nothrow) jade_scene();
   if (!s) return fail(JADE_ERR_NOMEM, "out of memory");
   s->device = device_id;
@@ -2116,6 +2467,7 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
   if (e == hipSuccess) e = upload(s->b_prefix, d->prefix_area, (size_t)d->n_triangles, s->stream);
   if (e == hipSuccess) e = upload(s->b_segs, d->obj_segs, (size_t)d->n_objects, s->stream);
   if (e == hipSuccess) e = upload(s->b_env, d->env_rgb, (size_t)3 * d->env_width * d->env_height, s->stream);
+  if (e == hipSuccess) e = upload(s->b_env_alias, env_alias.data(), env_alias.size(), s->stream);
   if (e == hipSuccess) e = upload(s->b_tnorm, tnorm.data(), tnorm.size(), s->stream);
   if (e == hipSuccess) e = upload(s->b_mats, mats.data(), mats.size(), s->stream);
   if (e == hipSuccess) e = upload(s->b_guide, guide.data(), guide.size(), s->stream);
@@ -2152,6 +2504,7 @@ int jade_scene_create(const jade_scene_desc* d, int device_id, jade_scene** out)
   s->dev.top_k = (uint32_t)std::min(n_internal, (int)JADE_LDS_TOP_NODES);
   s->dev.general_walk = missing_child ? 1u : 0u;
   s->dev.anyhit = want_anyhit ? s->b_anyhit.as<uint4>() : nullptr;
+  s->dev.env_alias = s->b_env_alias.as<uint4>();
   s->boxes_nested = nested;
   // Ray ordering pays when the traversal's records do not fit the XCDs' L2s (C5: 55 MB, k_trace bound by the rate of 64-B sector
   // misses: 4 235 -> 5 275 Mray/s); on a tree that does (C3: 3.8 MB) it costs more than it gives
@@ -2272,6 +2625,7 @@ int jade_render_begin(jade_scene* s, const jade_render_params* rp) {
     return fail(JADE_ERR_INVALID, "bad image size or tile partition");
   if (rp->walk != JADE_WALK_REFERENCE && rp->walk != JADE_WALK_EARLY_EXIT && rp->walk != JADE_WALK_EARLY_EXIT_CACHED)
     return fail(JADE_ERR_INVALID, "unknown walk (JADE_WALK_*)");
+  if (rp->env_sampling != JADE_ENV_REFERENCE && rp->env_sampling != JADE_ENV_IMPORTANCE) return fail(JADE_ERR_INVALID, "unknown env_sampling (JADE_ENV_*)");
   HIP_TRY(hipSetDevice(s->device));
   const int tx = (rp->width + JADE_TILE_SIZE - 1) / JADE_TILE_SIZE, ty = (rp->height + JADE_TILE_SIZE - 1) / JADE_TILE_SIZE;
   s->tile_ids.clear();
@@ -2336,6 +2690,7 @@ int jade_render_begin(jade_scene* s, const jade_render_params* rp) {
   int rc = setup_state(s, (int)npx64, rpp, nslots, sum_lanes);
   if (rc) return rc;
   s->ps.early_exit = rp->walk == JADE_WALK_EARLY_EXIT_CACHED ? 2u : rp->walk == JADE_WALK_EARLY_EXIT ? 1u : 0u;
+  s->ps.env_sampling = rp->env_sampling == JADE_ENV_IMPORTANCE ? 1u : 0u;
   memcpy(s->ps.eye, rp->eye, sizeof s->ps.eye);
   HIP_TRY(upload(s->b_tiles, s->tile_ids.data(), s->tile_ids.size(), s->stream));
   HIP_TRY(hipMemsetAsync(s->b_ctr.p, 0, sizeof(DevCounters) * JADE_CTR_SHARDS, s->stream));
@@ -2437,7 +2792,10 @@ static int run_passes(jade_scene* s, int64_t from_spp, uint32_t target_spp, bool
   bool closed_by_batch = false;  // the wait at the end of a batch was also the wait for the end of the step
   // k_tail: once the active list is short - and is not about to be carried over - ONE launch finishes its records (every wave
   // shades and traces its own 64 until they are out of samples).  The records' last rays have been traced: k_tail starts by shading.
-  const bool tail_ok = s->tun.tail && s->tun.tail_max > 0;
+  // k_shade with the records dealt by branch through LDS (k_shade_binned), unless switched off - or the render draws its
+  // environment rays by importance: a bounce may then emit no ray at all and is folded in on the spot, which the binned form does not do
+  auto shade_kernel = s->ps.env_sampling ? k_shade_envis : s->tun.shade_binned ? k_shade_binned : k_shade;
+  const bool tail_ok = s->tun.tail && s->tun.tail_max > 0 && !s->ps.env_sampling;  // (k_tail shades with the parity code only)
   const uint32_t tail_max = std::min<uint32_t>(s->tun.tail_max, (uint32_t)(s->b_queue.bytes / 4 / (size_t)std::max(s->ps.nslots, 1)));
   while (n_active) {
     const bool lean_mode = split_ok && (uint64_t)n_active * 4 >= (uint64_t)npix;
@@ -2489,7 +2847,7 @@ static int run_passes(jade_scene* s, int64_t from_spp, uint32_t target_spp, bool
       HIP_TRY(hipMemsetAsync(qc, 0, sizeof(QueueCtl) * B, s->stream));
       const int cur0 = cur;
       for (int j = 0; j < B; ++j) {
-        hipLaunchKernelGGL(k_shade, dim3(nbb), dim3(JADE_SHADE_BLOCK), 0, s->stream, s->dev, s->ps, s->rc, s->b_tiles.as<int32_t>(),
+        hipLaunchKernelGGL(shade_kernel, dim3(nbb), dim3(JADE_SHADE_BLOCK), 0, s->stream, s->dev, s->ps, s->rc, s->b_tiles.as<int32_t>(),
                            target_spp, s->b_active[cur].as<uint32_t>(), n_active, j ? &qc[j - 1].active : arm_dev,
                            s->b_active[cur ^ 1].as<uint32_t>(), s->b_queue.as<uint32_t>(), qc + j, s->b_ctr.as<DevCounters>(),
                            j ? qc + (j - 1) : (const QueueCtl*)nullptr, stop_below);
@@ -2601,7 +2959,7 @@ static int run_passes(jade_scene* s, int64_t from_spp, uint32_t target_spp, bool
       if (log_passes) HIP_TRY(hipEventRecord(sm, s->stream));
       // k_light has run every other record to the end of its samples, so the records this pass leaves active ARE the active
       // list (written over k_light's regions, which k_heavy_pack has emptied): no k_arm scan of all records after it
-      hipLaunchKernelGGL(k_shade, dim3(nb), dim3(JADE_SHADE_BLOCK), 0, s->stream, s->dev, s->ps, s->rc, s->b_tiles.as<int32_t>(),
+      hipLaunchKernelGGL(shade_kernel, dim3(nb), dim3(JADE_SHADE_BLOCK), 0, s->stream, s->dev, s->ps, s->rc, s->b_tiles.as<int32_t>(),
                          target_spp, s->b_active[1].as<uint32_t>(), 0u, &qc->heavy, s->b_active[0].as<uint32_t>(), s->b_queue.as<uint32_t>(), qc,
                          s->b_ctr.as<DevCounters>(), (const QueueCtl*)nullptr, 0u);
       have_list = true;
@@ -2613,13 +2971,13 @@ static int run_passes(jade_scene* s, int64_t from_spp, uint32_t target_spp, bool
                          s->b_queue.as<uint32_t>(), qc, s->b_ctr.as<DevCounters>());
       if (log_passes) HIP_TRY(hipEventRecord(sm, s->stream));
       // only a record that was active can be handed over: n_active bounds the grid, the count stays on the device
-      hipLaunchKernelGGL(k_shade, dim3(nb), dim3(JADE_SHADE_BLOCK), 0, s->stream, s->dev, s->ps, s->rc, s->b_tiles.as<int32_t>(),
+      hipLaunchKernelGGL(shade_kernel, dim3(nb), dim3(JADE_SHADE_BLOCK), 0, s->stream, s->dev, s->ps, s->rc, s->b_tiles.as<int32_t>(),
                          target_spp, s->b_active[1].as<uint32_t>(), 0u, &qc->heavy, (uint32_t*)nullptr, s->b_queue.as<uint32_t>(), qc,
                          s->b_ctr.as<DevCounters>(), (const QueueCtl*)nullptr, 0u);
       have_list = false;
     } else {
       if (log_passes) HIP_TRY(hipEventRecord(sm, s->stream));
-      hipLaunchKernelGGL(k_shade, dim3(nb), dim3(JADE_SHADE_BLOCK), 0, s->stream, s->dev, s->ps, s->rc, s->b_tiles.as<int32_t>(),
+      hipLaunchKernelGGL(shade_kernel, dim3(nb), dim3(JADE_SHADE_BLOCK), 0, s->stream, s->dev, s->ps, s->rc, s->b_tiles.as<int32_t>(),
                          target_spp, s->b_active[cur].as<uint32_t>(), n_active, (const uint32_t*)nullptr,
                          s->b_active[cur ^ 1].as<uint32_t>(), s->b_queue.as<uint32_t>(), qc, s->b_ctr.as<DevCounters>(), (const QueueCtl*)nullptr, 0u);
       cur ^= 1;

@@ -69,6 +69,30 @@ static __device__ __forceinline__ jvec3 sphere_dir(uint32_t* rng) {  // PathTrac
   return jv(sine_theta * cs, sine_theta * sn, cosine_theta);
 }
 
+// Environment importance sampling (jade_render_params.env_sampling = JADE_ENV_IMPORTANCE; NOT the reference's estimator): a texel of
+// the map by the alias method, a point in it uniformly, the direction SampleSphericalMap (PathTrace.cu:686-692) maps to that point.
+// ratio = (pdf of the reference's uniform hemisphere sampling, 1 / 2 pi) / (pdf of this direction): what the reference's weight is
+// multiplied with.  Four draws.
+static __device__ __forceinline__ jvec3 env_sample(const DevScene& S, uint32_t* rng, float* ratio) {
+  const uint32_t W = (uint32_t)S.env_w, N = W * (uint32_t)S.env_h;
+  uint32_t idx = (uint32_t)(jade_rand(rng) * (float)N);
+  idx = idx < N ? idx : N - 1u;
+  const float u2 = jade_rand(rng);
+  const uint4 e = S.env_alias[idx];
+  const bool own = u2 < jade_u2f(e.x);
+  const float pdf_n = jade_u2f(own ? e.z : e.w);  // the chosen texel's probability x N
+  idx = own ? idx : e.y;
+  const uint32_t j = idx / W, i = idx - j * W;
+  const float u = ((float)i + jade_rand(rng)) / (float)W, v = ((float)j + jade_rand(rng)) / (float)S.env_h;
+  const float theta = (float)JADE_PI_D * v, phi = (float)(2.0 * JADE_PI_D) * (u - 0.5f);
+  float st, ct, sp, cp;
+  jade_sincosf(theta, &st, &ct);
+  jade_sincosf(phi, &sp, &cp);
+  // pdf(direction) = pdf_n / (2 pi^2 sin theta); against 1 / (2 pi): ratio = pi sin theta / pdf_n
+  *ratio = (float)JADE_PI_D * st / pdf_n;
+  return jv(st * cp, ct, st * sp);
+}
+
 static __device__ __forceinline__ jvec3 tri_point(const jade_triangle* t, float rx, float ry) {
   jvec3 p1 = V3(t->p1);
   return jv_add(jv_add(p1, jv_scale(jv_sub(V3(t->p2), p1), rx)), jv_scale(jv_sub(V3(t->p3), p1), ry));
@@ -268,22 +292,22 @@ static __device__ bool begin_bounce_lean(const DevScene& S, PX& px, ShadeCtx& c,
   return bounce_mirror(px, c, ot, obj_emissive, ots.norm, l_final);
 }
 
-// Sample the bounce at the current vertex and emit its rays.  Returns false
-// if the path ended at this vertex (l_final holds the last l_dir).
-static __device__ bool begin_bounce(const DevScene& S, const Px& px, ShadeCtx& c, jvec3* l_final) {
-  const jade_triangle* T = S.tris;  // vertices only
+// Round 4: the bounce in two parts, so that k_shade can run the second one for records GROUPED BY BRANCH (bounce_classify by the
+// thread that holds the record, bounce_branch by whichever thread of the block the record is dealt to; k_shade, jade_hip.hip).
+// begin_bounce = the two in a row: the statements, and the order of the random draws, are the ones they always were.
+enum { BT_END = 0, BT_MIRROR, BT_DIFFUSE, BT_BSSRDF, BT_REFRACT, BT_N };
+// The head of the bounce: the emissive test (PathTrace.cu:916-920; BT_END: *l_final = the emission), then the draws that choose
+// the branch (:924-930).  BT_DIFFUSE covers the diffuse and the SSS-diffuse branch: stage and flags are set here.
+static __device__ __forceinline__ int bounce_classify(const DevScene& S, ShadeCtx& c, jvec3* l_final) {
   const ShadeTri ots = shade_tri(S, c.obj);
   const DevMaterial* ot = ots.m;
-  const int nE = S.n_emit;
-  const float RR_F = (float)JADE_RR_RATE_D;
   c.c_shaded += 1;
   jvec3 obj_emissive = V3(ot->emissive);
   if (obj_emissive.x > 1.4e-5f || obj_emissive.y > 1.4e-5f || obj_emissive.z > 1.4e-5f) {
     *l_final = obj_emissive;  // PathTrace.cu:916-920
-    return false;
+    return BT_END;
   }
   *l_final = jv(0, 0, 0);
-  const jvec3 n = ots.norm;
   float select_reflex_refract = jade_rand(&c.rng);
   if (select_reflex_refract < 0.5f && ot->refract_mode != JADE_NO_REFRACT) {
     if (ot->refract_mode == JADE_SUB_SURFACE) {
@@ -291,8 +315,35 @@ static __device__ bool begin_bounce(const DevScene& S, const Px& px, ShadeCtx& c
       if (select_reflex_refract < (float)JADE_SSS_RATE_D) {
         c.stage = ST_DIFFUSE;
         c.flags = STF_SSS;
-        goto diffuse_like;
+        return BT_DIFFUSE;
       }
+      return BT_BSSRDF;
+    }
+    return BT_REFRACT;
+  }
+  if (ot->reflex_mode == JADE_DIFFUSE) {
+    c.stage = ST_DIFFUSE;
+    c.flags = 0;
+    return BT_DIFFUSE;
+  }
+  return BT_MIRROR;
+}
+// The branch itself: its draws, its rays (written through px), stage / flags / n_emit_rays.  Returns false if the path ended at
+// this vertex (*l_final holds the last l_dir).  `type` is uniform over the waves k_shade runs it for.
+// ENVIS: jade_render_params.env_sampling = JADE_ENV_IMPORTANCE (compiled apart: the parity kernels carry none of its code)
+template <bool ENVIS = false>
+static __device__ __forceinline__ bool bounce_branch(int type, const DevScene& S, const Px& px, ShadeCtx& c, jvec3* l_final) {
+  const jade_triangle* T = S.tris;  // vertices only
+  const ShadeTri ots = shade_tri(S, c.obj);
+  const DevMaterial* ot = ots.m;
+  const int nE = S.n_emit;
+  const float RR_F = (float)JADE_RR_RATE_D;
+  const jvec3 n = ots.norm;
+  *l_final = jv(0, 0, 0);  // (as bounce_classify left it: a worker thread of k_shade brings its own)
+  if (type == BT_DIFFUSE) goto diffuse_like;
+  if (type == BT_MIRROR) return bounce_mirror(px, c, ot, V3(ot->emissive), n, l_final);  // ---- mirror, PathTrace.cu:1365-1405 ----
+  if (type == BT_BSSRDF) {
+    {
       // ---- BSSRDF, PathTrace.cu:1029-1178 ----
       const jade_obj_seg seg = S.segs[ot->obj_idx];
       const float u_area = jade_rand(&c.rng);
@@ -368,7 +419,20 @@ static __device__ bool begin_bounce(const DevScene& S, const Px& px, ShadeCtx& c
         px.set_limit(i, shadow_limit(et, random_point, sd));
         c.n_emit_rays++;
       }
-      {
+      uint32_t noenv = 0;
+      if (ENVIS) {  // (non-parity mode: by importance; a direction on the wrong side contributes nothing and is not traced)
+        float ratio;
+        const jvec3 ray_direction = env_sample(S, &c.rng, &ratio);
+        if (jv_dot(ray_direction, t_norm) * jv_dot(inner_direction, t_norm) < 0) {
+          px.set_hit(nE, -2);
+          noenv = STF_NOENV;
+        } else {
+          px.set_dir(nE, ray_direction);
+          px.set_limit(nE, JADE_INF_F);
+          px.set_auxi(__float_as_int(ratio));
+          c.n_emit_rays++;
+        }
+      } else {
         jvec3 ray_direction = sphere_dir(&c.rng);
         if (jv_dot(ray_direction, t_norm) * jv_dot(inner_direction, t_norm) < 0) ray_direction = jv_neg(ray_direction);
         px.set_dir(nE, ray_direction);
@@ -379,9 +443,9 @@ static __device__ bool begin_bounce(const DevScene& S, const Px& px, ShadeCtx& c
       if (jv_dot(ray_direction, t_norm) * jv_dot(inner_direction, t_norm) > 0) ray_direction = jv_neg(ray_direction);
       float rr_result = jade_rand(&c.rng);
       c.stage = ST_BSSRDF;
-      c.flags = 0;
+      c.flags = noenv;
       if (rr_result < RR_F) {
-        c.flags = STF_RR;
+        c.flags |= STF_RR;
         px.set_dir(nE + 1, ray_direction);
         px.set_hit(nE + 1, -1);
         c.n_emit_rays++;
@@ -390,7 +454,9 @@ static __device__ bool begin_bounce(const DevScene& S, const Px& px, ShadeCtx& c
       }
       return true;
     }
-    // ---- direct refraction entry, PathTrace.cu:1180-1199 ----
+  }
+  // ---- direct refraction entry, PathTrace.cu:1180-1199 ----
+  {
     {
       float triangle_miu = ot->refract_index;
       float R0 = (1 - triangle_miu) / (1 + triangle_miu) * (1 - triangle_miu) / (1 + triangle_miu);
@@ -411,13 +477,6 @@ static __device__ bool begin_bounce(const DevScene& S, const Px& px, ShadeCtx& c
       return true;
     }
   }
-  if (ot->reflex_mode == JADE_DIFFUSE) {
-    c.stage = ST_DIFFUSE;
-    c.flags = 0;
-    goto diffuse_like;
-  }
-  // ---- mirror, PathTrace.cu:1365-1405 ----
-  return bounce_mirror(px, c, ot, obj_emissive, n, l_final);
 
 diffuse_like:
   // ---- diffuse (:1266-1364) and SSS-diffuse (:931-1028): same ray set ----
@@ -442,7 +501,19 @@ diffuse_like:
         c.n_emit_rays++;
       }
     }
-    {
+    if (ENVIS) {  // (non-parity mode, as in the BSSRDF branch)
+      float ratio;
+      const jvec3 ray_direction = env_sample(S, &c.rng, &ratio);
+      if (jv_dot(ray_direction, n) * side < 0) {
+        px.set_hit(nE, -2);
+        c.flags |= STF_NOENV;
+      } else {
+        px.set_dir(nE, ray_direction);
+        px.set_limit(nE, JADE_INF_F);
+        px.set_auxi(__float_as_int(ratio));
+        c.n_emit_rays++;
+      }
+    } else {
       jvec3 ray_direction = sphere_dir(&c.rng);
       if (jv_dot(ray_direction, n) * side < 0) ray_direction = jv_neg(ray_direction);
       px.set_dir(nE, ray_direction);
@@ -462,6 +533,15 @@ diffuse_like:
     }
     return true;
   }
+}
+
+// Sample the bounce at the current vertex and emit its rays.  Returns false
+// if the path ended at this vertex (l_final holds the last l_dir).
+template <bool ENVIS = false>
+static __device__ bool begin_bounce(const DevScene& S, const Px& px, ShadeCtx& c, jvec3* l_final) {
+  const int type = bounce_classify(S, c, l_final);
+  if (type == BT_END) return false;
+  return bounce_branch<ENVIS>(type, S, px, c, l_final);
 }
 
 // Outcome of folding the pending rays' results into the path.
@@ -491,6 +571,7 @@ static __device__ __forceinline__ int consume_mirror(const DevScene& S, const PX
 // moved to a new vertex (c.obj/src/out updated); CONSUME_END: it ended with
 // *l_final; CONSUME_ZERO: pathTracing returned 0 (:1231); CONSUME_EMITTED: the
 // refraction loop issued its next ray.
+template <bool ENVIS = false>
 static __device__ int consume(const DevScene& S, const Px& px, ShadeCtx& c, jvec3* l_final) {
   const jade_triangle* T = S.tris;  // vertices only
   const int nE = S.n_emit;
@@ -520,11 +601,12 @@ static __device__ int consume(const DevScene& S, const Px& px, ShadeCtx& c, jvec
         l_dir = jv_add(l_dir, w);
       }
     }
-    if (px.hit(nE) < 0) {
+    if (ENVIS ? px.hit(nE) == -1 : px.hit(nE) < 0) {  // (-1: traced and nothing hit; -2: no environment ray this bounce - env_sampling only)
       jvec3 rd = px.dir(nE);
       jvec3 w = jv_mul(sample_hdr(S, rd), f);
       w = jv_scale(w, jade_fabs(jv_dot(n, rd)));
       w = jv_scale(jv_scale(w, 2.0f), PI_F);
+      if (ENVIS) w = jv_scale(w, __int_as_float(px.auxi()));  // x (1 / 2 pi) / pdf: the reference's weight is 1 / its own pdf
       l_dir = jv_add(l_dir, w);
     }
     l_dir = jv_scale(l_dir, sss ? (float)(k / JADE_SSS_RATE_D) : (float)k);
@@ -570,11 +652,12 @@ static __device__ int consume(const DevScene& S, const Px& px, ShadeCtx& c, jvec
         l_dir = jv_add(l_dir, w);
       }
     }
-    if (px.hit(nE) < 0) {
+    if (ENVIS ? px.hit(nE) == -1 : px.hit(nE) < 0) {
       jvec3 rd = px.dir(nE);
       float fresnel_rate_o = schlick_out(R0, jade_fabs(jv_dot(rd, t_norm)));
       jvec3 w = jv_mul(jv_scale(sample_hdr(S, rd), fresnel_rate_o), bssrdf);
       w = jv_scale(jv_scale(w, jade_fabs(jv_dot(t_norm, rd))), 2.0f);
+      if (ENVIS) w = jv_scale(w, __int_as_float(px.auxi()));
       l_dir = jv_add(l_dir, w);
     }
     l_dir = jv_scale(l_dir, (float)(k / (1 - JADE_SSS_RATE_D)));

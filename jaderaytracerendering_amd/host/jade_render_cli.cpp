@@ -56,7 +56,9 @@ static bool load_api(const std::string& path, Api& a) {
 static void usage() {
   fprintf(stderr,
           "usage: jade_render (--config NAME | --args render_args.txt) [--width W --height H] [--spp N]\n"
-          "                   [--out file.bmp|.ppm|.pfm] [--env sky|file.hdr] [--backend lib.so] [--device N] [--reference-walk]\n"
+          "                   [--out file.bmp|.ppm|.pfm] [--env sky|file.hdr] [--backend lib.so] [--device N] [--reference-walk] [--env-importance]\n"
+          "  --env-importance: environment-visibility rays drawn by the sky's luminance instead of uniformly (NOT the reference's samples: the\n"
+          "                    same image with less noise under a sky with a sun; the oracle backend refuses it)\n"
           "  --reference-walk: every hitBVH query walks what the reference walks (nodes_visited / tris_tested equal the oracle's);\n"
           "                    default: shadow / environment-visibility walks end at the hit that settles them - the same image, bit for bit\n"
           "  NAME: tiny, tinyjade, C1, C2, C3, C4, C5 (SURVEY.md section 8d); C3G = C3 with a DIR_REFRACT glass statue\n");
@@ -66,6 +68,7 @@ int main(int argc, char** argv) {
   std::string config, args_file, out = "RenderResultHip.bmp", backend, env;
   int width = 0, height = 0, spp = 0, device = 0;
   bool reference_walk = false;
+  bool env_importance = false;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     auto need = [&](const char* what) -> const char* {
@@ -82,6 +85,7 @@ int main(int argc, char** argv) {
     else if (a == "--backend") backend = need("--backend");
     else if (a == "--device") device = atoi(need("--device"));
     else if (a == "--reference-walk") reference_walk = true;
+    else if (a == "--env-importance") env_importance = true;
     else { usage(); return 2; }
   }
   if (config.empty() == args_file.empty()) { usage(); return 2; }
@@ -142,6 +146,7 @@ int main(int argc, char** argv) {
   rp.tile_nranks = 1;
   rp.device_id = device;
   rp.walk = reference_walk ? JADE_WALK_REFERENCE : JADE_WALK_EARLY_EXIT;
+  rp.env_sampling = env_importance ? JADE_ENV_IMPORTANCE : JADE_ENV_REFERENCE;  // (non-parity: another estimator of the same image; HIP backend only)
   std::vector<float> rgb((size_t)3 * rp.width * rp.height);
   std::vector<uint8_t> bgr((size_t)3 * rp.width * rp.height);
   jade_stats st;

@@ -1219,6 +1219,8 @@ int jade_render_begin(jade_scene* s, const jade_render_params* rp) {
   if (!s || !rp) return fail(JADE_ERR_INVALID, "null argument");
   if (rp->width <= 0 || rp->height <= 0 || rp->tile_nranks <= 0 || rp->tile_rank < 0 || rp->tile_rank >= rp->tile_nranks)
     return fail(JADE_ERR_INVALID, "bad image size or tile partition");
+  if (rp->env_sampling != JADE_ENV_REFERENCE) /* the oracle states the reference's estimator and nothing else (jade_rt.h, JADE_ENV_IMPORTANCE) */
+    return fail(JADE_ERR_UNSUPPORTED, "env_sampling: the oracle renders the reference's uniform hemisphere sampling only");
   size_t np = (size_t)rp->width * rp->height;
   free(s->sum);
   s->sum = NULL;

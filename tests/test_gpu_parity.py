@@ -235,10 +235,11 @@ def test_result_independent_of_shade_schedule(hip, monkeypatch):
         p.width, p.height = 40, 36
         ref = None
         #            split fused batch packet budget wide (k_trace_wide for the walk=1 frame) tail (k_tail finishes short lists; 0: passes to the end)
-        for v in (("1", "1", "1", "1", "32", "0", "1"), ("1", "1", "1", "0", "32", "1", "0"), ("1", "1", "1", "1", "3", "1", "1"), ("1", "1", "1", "1", "100000", "0", "0"),
-                  ("1", "0", "1", "1", "32", "1", "0"), ("0", "1", "1", "1", "32", "0", "1"), ("1", "1", "0", "1", "32", "1", "0"), ("1", "1", "0", "1", "32", "0", "1"),
-                  ("1", "0", "1", "1", "32", "0", "1")):
-            for key, val in zip(("JADE_SHADE_SPLIT", "JADE_FUSED", "JADE_BATCH", "JADE_LIGHT_PACKET", "JADE_PACKET_BUDGET", "JADE_WIDE", "JADE_TAIL"), v):
+        #            binned (k_shade deals its records by branch through LDS; 0: every thread runs its own record's whole bounce)
+        for v in (("1", "1", "1", "1", "32", "0", "1", "1"), ("1", "1", "1", "0", "32", "1", "0", "1"), ("1", "1", "1", "1", "3", "1", "1", "0"), ("1", "1", "1", "1", "100000", "0", "0", "0"),
+                  ("1", "0", "1", "1", "32", "1", "0", "1"), ("0", "1", "1", "1", "32", "0", "1", "1"), ("1", "1", "0", "1", "32", "1", "0", "1"), ("1", "1", "0", "1", "32", "0", "1", "0"),
+                  ("1", "0", "1", "1", "32", "0", "1", "0"), ("0", "1", "0", "1", "32", "0", "0", "1")):
+            for key, val in zip(("JADE_SHADE_SPLIT", "JADE_FUSED", "JADE_BATCH", "JADE_LIGHT_PACKET", "JADE_PACKET_BUDGET", "JADE_WIDE", "JADE_TAIL", "JADE_SHADE_BINNED"), v):
                 monkeypatch.setenv(key, val)
             with hip.scene(hs) as sc:
                 rgb, bgr, st = sc.render(p)

@@ -43,7 +43,8 @@ case "$what" in
   env)
     tag=$1; var=${2%%=*}; vals=${2#*=}; shift 2; O="$R/gpurun_out/$tag"; mkdir -p "$O"
     for v in ${vals//,/ }; do
-      env "$var=$v" timeout -k 10 600 python3 bench.py --no-cpu-baseline "$@" > "$O/${var}_$v.json" 2> "$O/${var}_$v.err" && line "$O/${var}_$v.json" "$var=$v" || { tail -20 "$O/${var}_$v.err"; exit 1; }
+      f=$(basename "$v")  # (a value may be a path: JADE_HIP_LIB=.../libjade_hip_x.so)
+      env "$var=$v" timeout -k 10 600 python3 bench.py --no-cpu-baseline "$@" > "$O/${var}_$f.json" 2> "$O/${var}_$f.err" && line "$O/${var}_$f.json" "$var=$f" || { tail -20 "$O/${var}_$f.err"; exit 1; }
     done ;;
   profile)
     bash tools/profile_set.sh "$@" ;;

@@ -15,11 +15,12 @@ fs=glob.glob("$O/pmc$lib/*/*counter_collection.csv")
 agg=collections.defaultdict(float); ns=collections.defaultdict(int); seen=set()
 for r in csv.DictReader(open(fs[0])):
     k=r["Kernel_Name"].split("(")[0]
-    if k not in ("k_trace","k_shade","k_shade_lean"): continue
+    if k not in ("k_trace","k_shade","k_shade_binned","k_shade_lean"): continue
     agg[(k,r["Counter_Name"])]+=float(r["Counter_Value"])
     if (k,r["Dispatch_Id"]) not in seen:
         seen.add((k,r["Dispatch_Id"])); ns[k]+=int(r["End_Timestamp"])-int(r["Start_Timestamp"])
-for k in ("k_trace","k_shade","k_shade_lean"):
+for k in ("k_trace","k_shade","k_shade_binned","k_shade_lean"):
+    if not ns[k]: continue
     g=lambda c: agg[(k,c)]
     print("$v %-13s ms %.1f VALU %.4g SALU %.4g lanes/inst %.1f valu_busy(4cyc) %.3f wait_any %.3f wait_inst %.3f" % (k, ns[k]*1e-6, g("SQ_INSTS_VALU"), g("SQ_INSTS_SALU"), g("SQ_THREAD_CYCLES_VALU")/g("SQ_INSTS_VALU"), 4*g("SQ_ACTIVE_INST_VALU")/1024/(g("SQ_BUSY_CU_CYCLES")/256), g("SQ_WAIT_ANY")/g("SQ_WAVE_CYCLES"), g("SQ_WAIT_INST_ANY")/g("SQ_WAVE_CYCLES")))
 PY
