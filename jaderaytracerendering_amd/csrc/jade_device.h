@@ -177,6 +177,16 @@ struct PathState {
   // hit is wanted; JADE_INF_F = any recorded hit (hitArray records a hit only below INF, PathTrace.cu:787); a shadow ray carries
   // the distance at which hitTriangle meets the emitter it aims at (JADE_INF_F if it does not: then no hit can make it
   // visible).  -2 (also a NaN) = no ray in this slot.  With the reference walk k_trace ignores the word.
+  // Ray records (round 4): the first rayq_cap entries of the ray queue also exist as 48-B records - what k_trace's refill needs of a
+  // ray, computed by the kernel that queued it: {origin, skip word (walk_begin's skipx)} {1 / d, limit} {normalize(d), slot number} -
+  // read back coalesced in ONE round trip instead of queue entry -> origin + slot (two, both scattered) + six divisions and a square
+  // root per ray.  Entries beyond rayq_cap (and every launch with rayq_cap = 0: k_tail, ordered queues, jade_trace_rays) take the
+  // index alone, as before.  Same functions on the same values, so the same bits.
+  float4* rayq;
+  uint32_t rayq_cap;
+  // An ORDERED queue (k_ray_keys + rocPRIM sort; scenes whose tree does not fit the L2) holds queue POSITIONS in the order k_trace is
+  // to take them, not slot numbers: position v's ray is record v (v < rayq_cap) or entry v of the index queue, idxq (otherwise).
+  const uint32_t* idxq;  // null = the queue k_trace is given IS the index queue, taken in its own order
   uint32_t env_sampling;  // JADE_ENV_*: 1 = environment rays drawn by importance (non-parity mode)
   uint32_t early_exit;  // 0: the reference's walk; 1: early exits; 2: early exits + the occluder cache (JADE_WALK_EARLY_EXIT_CACHED)
 };

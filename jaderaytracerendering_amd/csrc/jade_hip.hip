@@ -48,6 +48,30 @@
 
 // ------------------------------------------------------------------ kernels --
 
+#ifndef JADE_TRACE_NT
+#define JADE_TRACE_NT 1 /* k_trace reads and writes the ray records with non-temporal hints */
+#endif
+#if JADE_TRACE_NT
+#define NT_LD(p) __builtin_nontemporal_load(p)
+#define NT_ST(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define NT_LD(p) (*(p))
+#define NT_ST(p, v) (*(p) = (v))
+#endif
+#if JADE_TRACE_PROFILE
+__device__ unsigned long long g_trace_prof[PL_N];  // development profile of k_trace: shader clocks per piece of the loop, summed over waves
+#endif
+typedef float jade_v4f __attribute__((ext_vector_type(4)));
+static __device__ __forceinline__ float4 nt_ld4(const float4* p) {
+  const jade_v4f v = NT_LD(reinterpret_cast<const jade_v4f*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+static __device__ __forceinline__ void nt_st4(float4* p, float x, float y, float z, float w) {
+  const jade_v4f v = {x, y, z, w};
+  NT_ST(reinterpret_cast<jade_v4f*>(p), v);
+}
+
+
 struct alignas(8) QueueCtl {
   uint32_t count;   // rays emitted by the last shade pass          } one 64-bit word: k_shade reserves its queue
   uint32_t active;  // records with rays in flight after that pass } and list space with ONE atomic per block
@@ -431,10 +455,32 @@ static __device__ __forceinline__ void shade_tail(const PathState& P, int p, uin
     uint32_t wbase = sh_base[0];
     for (int i = 0; i < w; ++i) wbase += sh_rays[i];
     const int used = !live ? 0 : (st == ST_DIFFUSE || st == ST_BSSRDF) ? P.nslots : 1;
+    // ... and, for the first rayq_cap entries, the ray as k_trace's refill needs it (PathState.rayq): origin and source triangle are
+    // the record's (camera rays: the eye), direction and limit the slot's, just written by this thread
+    jvec3 ro = jv(0, 0, 0);
+    int32_t rskip = -1;
+    if (used && P.rayq_cap) {
+      const float4 og = P.orgs[p];
+      rskip = __float_as_int(og.w);
+      ro = rskip == JADE_SKIP_CAMERA ? jv(P.eye[0], P.eye[1], P.eye[2]) : jv(og.x, og.y, og.z);
+    }
     for (int k = 0; k < P.nslots; ++k) {
-      const bool q = k < used && reinterpret_cast<const int*>(P.slot + ((size_t)p * P.nslots + k) * 2)[3] != -2;  // (-2: no ray in this slot; anything else: the queued ray's limit, jade_device.h)
+      const float4* sl = P.slot + ((size_t)p * P.nslots + k) * 2;
+      const bool q = k < used && reinterpret_cast<const int*>(sl)[3] != -2;  // (-2: no ray in this slot; anything else: the queued ray's limit, jade_device.h)
       const unsigned long long m = __ballot(q);
-      if (q) queue[wbase + (uint32_t)__popcll(m & below)] = (uint32_t)p * (uint32_t)P.nslots + (uint32_t)k;
+      const uint32_t pos = wbase + (uint32_t)__popcll(m & below);
+      const uint32_t e = (uint32_t)p * (uint32_t)P.nslots + (uint32_t)k;
+      if (q) queue[pos] = e;
+      if (q && pos < P.rayq_cap) {
+        const float4 dv = sl[0];
+        jvec3 inv, dn;
+        uint32_t skipx;
+        walk_prepare(ro, jv(dv.x, dv.y, dv.z), rskip, &inv, &dn, &skipx);
+        float4* rq = P.rayq + (size_t)pos * 3;
+        nt_st4(rq, ro.x, ro.y, ro.z, __uint_as_float(skipx));
+        nt_st4(rq + 1, inv.x, inv.y, inv.z, P.early_exit ? dv.w : __int_as_float(-1));
+        nt_st4(rq + 2, dn.x, dn.y, dn.z, __uint_as_float(e));
+      }
       wbase += (uint32_t)__popcll(m);
     }
   }
@@ -801,9 +847,10 @@ __global__ __launch_bounds__(JADE_LEAN_BLOCK) void k_shade_lean(DevScene S, Path
 // sits in the L2, a wave whose rays read the same lines is 2.6 % faster and the sort costs 9 %; it is meant for scenes whose
 // geometry does not fit the L2 (C5: k_trace is bound by the rate of 64-B sector misses there).
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void k_ray_keys(PathState P, const uint32_t* queue, uint32_t n, uint32_t* keys, int n_emit, uint32_t tri_bits) {  // tri_bits: bits of the largest triangle index
+__global__ void k_ray_keys(PathState P, const uint32_t* queue, uint32_t n, uint32_t* keys, uint32_t* positions, int n_emit, uint32_t tri_bits) {  // tri_bits: bits of the largest triangle index
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  positions[i] = i;  // what the sort moves with the key: the entry's POSITION (PathState.idxq)
   const uint32_t e = queue[i];
   const uint32_t p = e / (uint32_t)P.nslots, k = e - p * (uint32_t)P.nslots;
   const uint32_t st = P.hdr[p].z & 255u;
@@ -818,28 +865,6 @@ __global__ void k_ray_keys(PathState P, const uint32_t* queue, uint32_t n, uint3
 }
 
 #define JADE_CTL_RING 96 /* QueueCtl records: entry 0 for passes the host follows one by one, all of them for a batch of passes (round 4: 96 - a 1024-spp step of C3 is ~65 passes down to its carry-over point, the flush ~65 more down to k_tail's threshold: one batch, one wait each; the launches behind the stop are empty) */
-#ifndef JADE_TRACE_NT
-#define JADE_TRACE_NT 1 /* k_trace reads and writes the ray records with non-temporal hints */
-#endif
-#if JADE_TRACE_NT
-#define NT_LD(p) __builtin_nontemporal_load(p)
-#define NT_ST(p, v) __builtin_nontemporal_store((v), (p))
-#else
-#define NT_LD(p) (*(p))
-#define NT_ST(p, v) (*(p) = (v))
-#endif
-#if JADE_TRACE_PROFILE
-__device__ unsigned long long g_trace_prof[PL_N];  // development profile of k_trace: shader clocks per piece of the loop, summed over waves
-#endif
-typedef float jade_v4f __attribute__((ext_vector_type(4)));
-static __device__ __forceinline__ float4 nt_ld4(const float4* p) {
-  const jade_v4f v = NT_LD(reinterpret_cast<const jade_v4f*>(p));
-  return make_float4(v.x, v.y, v.z, v.w);
-}
-static __device__ __forceinline__ void nt_st4(float4* p, float x, float y, float z, float w) {
-  const jade_v4f v = {x, y, z, w};
-  NT_ST(reinterpret_cast<jade_v4f*>(p), v);
-}
 #ifndef JADE_TRACE_WAVES
 #define JADE_TRACE_WAVES 5 /* waves per SIMD the register allocation leaves room for: 5 = at most 96 VGPRs (12 bytes of scratch) and 5 x 31 KB of LDS per CU.  Round 3, same process, C3 / statue close-up: 4 waves (102 VGPRs) 133.6 / 1037 ms of k_trace per 256-spp step, 5 waves 126.9 / 983 (round 2's "5 and 6 blocks per CU are no faster" was measured on a 102-VGPR build, which the hardware never ran at more than 4) */
 #endif
@@ -853,6 +878,23 @@ typedef uint32_t jade_v4u __attribute__((ext_vector_type(4)));
 static __device__ __forceinline__ uint4 ld_anyhit(const uint4* p) {
   const jade_v4u v = NT_LD(reinterpret_cast<const jade_v4u*>(p));
   return make_uint4(v.x, v.y, v.z, v.w);
+}
+// occluder cache: a query's walk starts with the cached subtrees - the lane's stack begins with them instead of the root
+static __device__ __forceinline__ void anyhit_seed(WalkState& r, const LdsStack& stk, uint4 c) {
+  uint32_t cur = JADE_REF_NONE, sp = stk.col;
+  const uint32_t e4[4] = {c.w, c.z, c.y, c.x};  // way 0 is walked first: the others go under it
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bool have = e4[i] != 0u, push = have && cur != JADE_REF_NONE;
+    lds_st(push ? sp : stk.col + TW_DUMMY * JADE_COL_STRIDE, cur);
+    sp += push ? JADE_COL_STRIDE : 0u;
+    cur = have ? e4[i] - 1u : cur;
+  }
+  if (cur != JADE_REF_NONE) {
+    r.cur = cur;
+    r.sp = sp;
+    r.skipx |= JADE_ATTEMPT;
+  }
 }
 // WIDE: the walk may take wide units (jade_trace.h, "Wide walk"): k_trace_wide, launched instead of k_trace for renders with
 // early exits on trees that have wide records.
@@ -1074,8 +1116,27 @@ static __device__ __forceinline__ void trace_body(const DevScene& S, const PathS
         const uint32_t avail = lend - lbase;
         const uint32_t take = (uint32_t)n_idle < avail ? (uint32_t)n_idle : avail;
         const uint32_t rank = wt.rank_in(idle);
-        if (!active && rank < take) {
-          my_e = NT_LD(&queue[lbase + rank]);
+        // (an ordered queue holds positions: PathState.idxq)
+        uint32_t qpos = lbase + rank;
+        if (!TAIL && P.idxq && !active && rank < take) qpos = NT_LD(&queue[lbase + rank]);
+        if (!TAIL && !active && rank < take && qpos < P.rayq_cap) {
+          // ---- the ray as a record (PathState.rayq): three 16-B loads (coalesced unless the queue is ordered), nothing to compute
+          const float4* rq = P.rayq + (size_t)qpos * 3;
+          const float4 r0 = nt_ld4(rq), r1 = nt_ld4(rq + 1), r2 = nt_ld4(rq + 2);
+          my_e = __float_as_uint(r2.w);
+          const uint32_t skipx = __float_as_uint(r0.w);
+          const uint32_t src = skipx & JADE_SKIP_MASK;
+          const bool anyq = anyhit && r1.w == r1.w && src != JADE_SKIP_MASK;
+          uint4 c = make_uint4(0u, 0u, 0u, 0u);
+          if (anyq) {
+            const uint32_t p = my_e / (uint32_t)P.nslots;
+            c = ld_anyhit(S.anyhit + (size_t)src * JADE_ANYHIT_KEYS + anyhit_key(my_e - p * (uint32_t)P.nslots, (uint32_t)S.n_emit, jv(r2.x, r2.y, r2.z)));
+          }
+          walk_begin_prepared(r, stk, S, jv(r0.x, r0.y, r0.z), jv(r1.x, r1.y, r1.z), jv(r2.x, r2.y, r2.z), skipx, r1.w);
+          if (anyq && (int32_t)skipx >= 0) anyhit_seed(r, stk, c);
+          active = true;
+        } else if (!active && rank < take) {
+          my_e = (!TAIL && P.idxq) ? NT_LD(&P.idxq[qpos]) : NT_LD(&queue[lbase + rank]);
           const uint32_t p = my_e / (uint32_t)P.nslots;  // the entry is the slot number p * nslots + k
           const float4 og = nt_ld4(&P.orgs[p]);
           const int32_t skip = __float_as_int(og.w);
@@ -1089,22 +1150,7 @@ static __device__ __forceinline__ void trace_body(const DevScene& S, const PathS
           uint4 c = make_uint4(0u, 0u, 0u, 0u);
           if (anyq) c = ld_anyhit(S.anyhit + (size_t)skip * JADE_ANYHIT_KEYS + anyhit_key(my_e - p * (uint32_t)P.nslots, (uint32_t)S.n_emit, d));
           walk_begin(r, stk, S, o, d, skip, P.early_exit ? dv.w : __int_as_float(-1));
-          if (anyq && (int32_t)r.skipx >= 0) {  // (a ray with a non-finite 1/d takes the NaN-faithful walk from the root)
-            uint32_t cur = JADE_REF_NONE, sp = stk.col;
-            const uint32_t e4[4] = {c.w, c.z, c.y, c.x};  // way 0 is walked first: the others go under it
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const bool have = e4[i] != 0u, push = have && cur != JADE_REF_NONE;
-              lds_st(push ? sp : stk.col + TW_DUMMY * JADE_COL_STRIDE, cur);
-              sp += push ? JADE_COL_STRIDE : 0u;
-              cur = have ? e4[i] - 1u : cur;
-            }
-            if (cur != JADE_REF_NONE) {
-              r.cur = cur;
-              r.sp = sp;
-              r.skipx |= JADE_ATTEMPT;
-            }
-          }
+          if (anyq && (int32_t)r.skipx >= 0) anyhit_seed(r, stk, c);  // (a ray with a non-finite 1/d takes the NaN-faithful walk from the root)
           active = true;
         }
         V += take;  // the root record of every ray started
@@ -1885,6 +1931,7 @@ struct Tunables {
   int packet_budget = JADE_PACKET_BUDGET;  // JADE_PACKET_BUDGET: records a packet may read before it is given up and walked per lane
   int wide_mode = -1;         // JADE_WIDE: with early exits k_trace walks four grandchildren per visit (k_trace_wide): 1 always, 0 never, unset =
                               // when the traversal's records do not fit the L2 (the rule of sort_mode; jade_scene_create then builds wide records)
+  bool ray_records = true;    // JADE_RAY_RECORDS=0: k_trace's refill gathers every ray through its queue entry (before round 4)
   bool shade_binned = false;  // JADE_SHADE_BINNED=1: k_shade_binned - the records of a block dealt by branch through LDS (measured level with k_shade: DESIGN.md 3.4)
   bool tail = true;           // JADE_TAIL=0: no k_tail - the last paths are finished by passes, as before round 4
   uint32_t tail_max = JADE_TAIL_MAX;  // JADE_TAIL_MAX: active records at or below which k_tail takes over
@@ -1896,6 +1943,7 @@ struct Tunables {
     if (const char* e = getenv("JADE_TAIL_MAX")) tail_max = (uint32_t)atoi(e);
     auto flag1 = [](const char* n) { const char* e = getenv(n); return e && atoi(e) > 0; };
     shade_binned = flag1("JADE_SHADE_BINNED");
+    ray_records = !flag0("JADE_RAY_RECORDS");
     shade_split = !flag0("JADE_SHADE_SPLIT");
     fused = shade_split && !flag0("JADE_FUSED");
     batching = !flag0("JADE_BATCH");
@@ -1929,10 +1977,10 @@ struct jade_scene {
   jade_render_params rp{};
   RenderConst rc{};
   PathState ps{};
-  DevBuf b_sortkey, b_sortkey2, b_sortq, b_sorttmp;  // JADE_SORT: keys in / out, the ordered queue, rocPRIM's temporary storage
+  DevBuf b_sortkey, b_sortkey2, b_sortpos, b_sortq, b_sorttmp;  // JADE_SORT: keys in / out, the entries' positions, the ordered queue (of positions), rocPRIM's temporary storage
   size_t sort_cap = 0, sort_tmp_bytes = 0;
   double sort_ms = 0;
-  DevBuf b_state, b_sum, b_tiles, b_queue, b_active[2], b_ctl, b_ctr, b_spill, b_out_rgb, b_out_bgr, b_wavecnt;
+  DevBuf b_state, b_sum, b_tiles, b_queue, b_rayq, b_active[2], b_ctl, b_ctr, b_spill, b_out_rgb, b_out_bgr, b_wavecnt;
   std::vector<int32_t> tile_ids;
   int trace_blocks = 0;
   int trace_blocks_wide = 0;  // ... of k_trace_wide (fewer waves per SIMD)
@@ -2597,6 +2645,15 @@ static int setup_state(jade_scene* s, int npx, int rpp, int nslots, int sum_lane
   P.sum = s->b_sum.as<float>(); P.ctx = (float4*)(b + o_ctx); P.aux = (float4*)(b + o_aux); P.orgs = (float4*)(b + o_orgs);
   P.slot = (float4*)(b + o_slot);
   HIP_TRY(s->b_queue.alloc(K * N * 4));
+  // ray records for the head of the queue (PathState.rayq): as many as an eighth of all slots - a pass after the fused first one
+  // queues rays for a few per cent of the records - but every slot of a small render; none when switched off
+  {
+    size_t cap = s->tun.ray_records ? std::max<size_t>((K * N + 7) / 8, std::min<size_t>(K * N, (size_t)1 << 22)) : 0;
+    cap = std::min<size_t>(cap, K * N);
+    if (cap) HIP_TRY(s->b_rayq.alloc(cap * 48));
+    P.rayq = cap ? s->b_rayq.as<float4>() : nullptr;
+    P.rayq_cap = (uint32_t)std::min<size_t>(cap, 0xffffffffu);
+  }
   // b_active[0] doubles as k_light's per-wave hand-over regions: up to 64 records of slack per wave of its grid
   const size_t first_pass_blocks = (size_t)std::max(s->light_blocks, s->packet_blocks);
   HIP_TRY(s->b_active[0].alloc((N + first_pass_blocks * JADE_TRACE_BLOCK + 64) * 4));
@@ -2609,6 +2666,7 @@ static int setup_state(jade_scene* s, int npx, int rpp, int nslots, int sum_lane
     HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, cap, 0u, 32u, s->stream));
     HIP_TRY(s->b_sortkey.alloc(cap * 4));
     HIP_TRY(s->b_sortkey2.alloc(cap * 4));
+    HIP_TRY(s->b_sortpos.alloc(cap * 4));
     HIP_TRY(s->b_sortq.alloc(cap * 4));
     HIP_TRY(s->b_sorttmp.alloc(tmp));
     s->sort_tmp_bytes = tmp;
@@ -2637,7 +2695,7 @@ int jade_render_begin(jade_scene* s, const jade_render_params* rp) {
   // Records per pixel: as many paths in flight as JADE_RECORD_MEMORY of the free device memory holds (the
   // partial sums come out of the same share), whatever the image share of this GPU: more records = fewer,
   // wider passes.  288 GB is what makes 530 M paths (112 GB) for a full 1080p frame affordable.
-  const double bytes_per_record = 4.0 * (30 + 9 * nslots);  // PathState (a slot is two float4) + queue entry + two list entries
+  const double bytes_per_record = 4.0 * (30 + 9 * nslots) + (s->tun.ray_records ? 6.0 * nslots : 0.0);  // PathState (a slot is two float4) + queue entry + two list entries + 48-B ray records for an eighth of the slots
   // partial sums per pixel: one lane per sample up to JADE_SAMPLE_LANES, never more than the render was announced with
   // (rounded up to a power of two): a 1-spp 4K frame is 100 MB of sums, not 102 GB
   int sum_lanes = JADE_SAMPLE_LANES;
@@ -2646,7 +2704,7 @@ int jade_render_begin(jade_scene* s, const jade_render_params* rp) {
   const double sums_bytes = 12.0 * sum_lanes * (double)npx64;
   size_t mem_free = 0, mem_total = 0;
   HIP_TRY(hipMemGetInfo(&mem_free, &mem_total));
-  mem_free += s->b_state.bytes + s->b_sum.bytes + s->b_queue.bytes + s->b_active[0].bytes + s->b_active[1].bytes;  // ours to reuse
+  mem_free += s->b_state.bytes + s->b_sum.bytes + s->b_queue.bytes + s->b_rayq.bytes + s->b_active[0].bytes + s->b_active[1].bytes;  // ours to reuse
   // the caller's bound (jade_render_params.max_state_bytes) replaces the default share of the free memory
   double state_budget = JADE_RECORD_MEMORY * (double)mem_free;
   if (rp->max_state_bytes) state_budget = std::min((double)rp->max_state_bytes, 0.95 * (double)mem_free);
@@ -3013,7 +3071,7 @@ static int run_passes(jade_scene* s, int64_t from_spp, uint32_t target_spp, bool
       uint32_t tri_bits = 1;
       while (tri_bits < 23 && ((uint32_t)(s->dev.n_tris - 1) >> tri_bits)) ++tri_bits;
       hipLaunchKernelGGL(k_ray_keys, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->ps, s->b_queue.as<uint32_t>(), n, s->b_sortkey.as<uint32_t>(),
-                         s->n_emit, tri_bits);
+                         s->b_sortpos.as<uint32_t>(), s->n_emit, tri_bits);
       // The temporary storage was sized once, for (sort_cap entries, bits 0..32).  rocPRIM's need shrinks with the length and with
       // the bit range (fewer digit places, fewer look-back states; a short queue takes its merge-sort path: two buffers of n), and a
       // buffer that is too small is an error return, not a fault (rocprim/detail/temp_storage.hpp: partition) - asked again here,
@@ -3022,11 +3080,13 @@ static int run_passes(jade_scene* s, int64_t from_spp, uint32_t target_spp, bool
       HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, 0u, 32u, s->stream));
       if (need > s->sort_tmp_bytes) return fail(JADE_ERR_DEVICE, "ray-queue sort: temporary storage smaller than rocPRIM asks for this length (internal sizing error)");
       size_t tmp = s->sort_tmp_bytes;
-      HIP_TRY(rocprim::radix_sort_pairs(s->b_sorttmp.p, tmp, s->b_sortkey.as<uint32_t>(), s->b_sortkey2.as<uint32_t>(), s->b_queue.as<uint32_t>(),
+      HIP_TRY(rocprim::radix_sort_pairs(s->b_sorttmp.p, tmp, s->b_sortkey.as<uint32_t>(), s->b_sortkey2.as<uint32_t>(), s->b_sortpos.as<uint32_t>(),
                                         s->b_sortq.as<uint32_t>(), (size_t)n, 0u, 32u, s->stream));
-      trace_queue = s->b_sortq.as<uint32_t>();
+      trace_queue = s->b_sortq.as<uint32_t>();  // positions, in the order k_trace is to take them (PathState.idxq)
     }
-    hipLaunchKernelGGL(trace_wide(s->dev, s->ps) ? k_trace_wide : k_trace, dim3((unsigned)(trace_wide(s->dev, s->ps) ? s->trace_blocks_wide : s->trace_blocks)), dim3(JADE_TRACE_BLOCK), 0, s->stream, s->dev, s->ps,
+    PathState tps = s->ps;
+    tps.idxq = trace_queue != s->b_queue.as<uint32_t>() ? s->b_queue.as<uint32_t>() : nullptr;
+    hipLaunchKernelGGL(trace_wide(s->dev, s->ps) ? k_trace_wide : k_trace, dim3((unsigned)(trace_wide(s->dev, s->ps) ? s->trace_blocks_wide : s->trace_blocks)), dim3(JADE_TRACE_BLOCK), 0, s->stream, s->dev, tps,
                        trace_queue, qc, s->b_spill.as<uint32_t>(), s->b_ctr.as<DevCounters>(),
                        trace_chunk(s, host_ctl[0]));
     HIP_TRY(hipGetLastError());
@@ -3163,8 +3223,8 @@ int jade_render_query(jade_scene* s, int what, int64_t* value) {
   switch (what) {
     case JADE_Q_RECORDS_PER_PIXEL: *value = s->ps.npix ? s->ps.rpp : 0; return JADE_OK;
     case JADE_Q_STATE_BYTES:
-      *value = s->ps.npix ? (int64_t)(s->b_state.bytes + s->b_sum.bytes + s->b_queue.bytes + s->b_active[0].bytes + s->b_active[1].bytes +
-                                      s->b_wavecnt.bytes + s->b_spill.bytes + s->b_sortkey.bytes + s->b_sortkey2.bytes + s->b_sortq.bytes + s->b_sorttmp.bytes)
+      *value = s->ps.npix ? (int64_t)(s->b_state.bytes + s->b_sum.bytes + s->b_queue.bytes + s->b_rayq.bytes + s->b_active[0].bytes + s->b_active[1].bytes +
+                                      s->b_wavecnt.bytes + s->b_spill.bytes + s->b_sortkey.bytes + s->b_sortkey2.bytes + s->b_sortpos.bytes + s->b_sortq.bytes + s->b_sorttmp.bytes)
                           : 0;
       return JADE_OK;
     case JADE_Q_SUM_LANES: *value = s->ps.npix ? s->ps.sum_lanes : 0; return JADE_OK;

@@ -809,6 +809,33 @@ static __device__ __forceinline__ void walk_begin(WalkState& r, const LdsStack& 
   r.pre = node_fetch<JADE_TRACE_TOP_NODES>(r.cur, S, stk);
 #endif
 }
+// walk_begin's arithmetic on its own - what a ray record carries (jade_device.h, PathState.rayq): 1 / d, normalize(d) and the skip word
+static __device__ __forceinline__ void walk_prepare(jvec3 o, jvec3 d, int32_t skip, jvec3* inv_out, jvec3* dn_out, uint32_t* skipx_out) {
+  const jvec3 inv = jv(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  *dn_out = jv_normalize(d);
+  const bool exact = !(finite_f(inv.x) && finite_f(inv.y) && finite_f(inv.z)) || !finite_f(o.x) || !finite_f(o.y) || !finite_f(o.z);
+  *skipx_out = (skip < 0 ? JADE_SKIP_MASK : (uint32_t)skip) | (exact ? 0x80000000u : 0u);
+  *inv_out = inv;
+}
+// ... and walk_begin from such a record
+static __device__ __forceinline__ void walk_begin_prepared(WalkState& r, const LdsStack& stk, const DevScene& S, jvec3 o, jvec3 inv, jvec3 dn, uint32_t skipx, float limit) {
+  r.od.a = f2{o.x, o.y};
+  r.od.b = f2{o.z, dn.x};
+  r.od.c = f2{dn.y, dn.z};
+  r.skipx = skipx;
+  r.sp = stk.col;
+  r.pushed = 0;
+  r.cur = S.root_ref;
+  r.inv = inv;
+  lds_putf(stk, TW_BEST_DIST, JADE_INF_F);
+  lds_put(stk, TW_BEST_SEQ, 0xffffffffu);
+  lds_put(stk, TW_BEST_REF, 0xffffffffu);
+  lds_st_v(stk.col + TW_FINISHED * JADE_COL_STRIDE, 0u);
+  lds_putf(stk, TW_LIMIT, limit);
+#if JADE_PREFETCH
+  r.pre = node_fetch<JADE_TRACE_TOP_NODES>(r.cur, S, stk);
+#endif
+}
 // The same ray once more, from the root, with nothing found yet (k_trace: an attempt over the cached subtrees that found no answer;
 // a wide walk that met a tie).  The ray itself - origin, directions, source triangle, its limit in the column - stays as it is.
 static __device__ __forceinline__ void walk_restart(WalkState& r, const LdsStack& stk, const DevScene& S) {

@@ -236,10 +236,11 @@ def test_result_independent_of_shade_schedule(hip, monkeypatch):
         ref = None
         #            split fused batch packet budget wide (k_trace_wide for the walk=1 frame) tail (k_tail finishes short lists; 0: passes to the end)
         #            binned (k_shade deals its records by branch through LDS; 0: every thread runs its own record's whole bounce)
-        for v in (("1", "1", "1", "1", "32", "0", "1", "1"), ("1", "1", "1", "0", "32", "1", "0", "1"), ("1", "1", "1", "1", "3", "1", "1", "0"), ("1", "1", "1", "1", "100000", "0", "0", "0"),
-                  ("1", "0", "1", "1", "32", "1", "0", "1"), ("0", "1", "1", "1", "32", "0", "1", "1"), ("1", "1", "0", "1", "32", "1", "0", "1"), ("1", "1", "0", "1", "32", "0", "1", "0"),
-                  ("1", "0", "1", "1", "32", "0", "1", "0"), ("0", "1", "0", "1", "32", "0", "0", "1")):
-            for key, val in zip(("JADE_SHADE_SPLIT", "JADE_FUSED", "JADE_BATCH", "JADE_LIGHT_PACKET", "JADE_PACKET_BUDGET", "JADE_WIDE", "JADE_TAIL", "JADE_SHADE_BINNED"), v):
+        #            records (k_trace refills from 48-B ray records the shading kernels wrote; 0: it gathers each ray through its queue entry)
+        for v in (("1", "1", "1", "1", "32", "0", "1", "1", "1"), ("1", "1", "1", "0", "32", "1", "0", "1", "0"), ("1", "1", "1", "1", "3", "1", "1", "0", "1"), ("1", "1", "1", "1", "100000", "0", "0", "0", "0"),
+                  ("1", "0", "1", "1", "32", "1", "0", "1", "1"), ("0", "1", "1", "1", "32", "0", "1", "1", "0"), ("1", "1", "0", "1", "32", "1", "0", "1", "1"), ("1", "1", "0", "1", "32", "0", "1", "0", "0"),
+                  ("1", "0", "1", "1", "32", "0", "1", "0", "1"), ("0", "1", "0", "1", "32", "0", "0", "1", "1")):
+            for key, val in zip(("JADE_SHADE_SPLIT", "JADE_FUSED", "JADE_BATCH", "JADE_LIGHT_PACKET", "JADE_PACKET_BUDGET", "JADE_WIDE", "JADE_TAIL", "JADE_SHADE_BINNED", "JADE_RAY_RECORDS"), v):
                 monkeypatch.setenv(key, val)
             with hip.scene(hs) as sc:
                 rgb, bgr, st = sc.render(p)
