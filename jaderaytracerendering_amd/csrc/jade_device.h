@@ -152,7 +152,7 @@ struct PathState {
                         // flight, done: samples this record has finished, stage | depth << 8 | flags << 16, 0}.  Read in record
                         // order by k_light (coalesced); for k_shade, whose records are scattered, one sector instead of three
   int32_t sum_lanes;    // partial sums kept per pixel: min(JADE_SAMPLE_LANES, announced spp rounded up to a power of two) >= rpp
-  float* sum;           // [3][sum_lanes * npx] partial radiance sums per (lane, pixel); sample s adds into lane s % JADE_SAMPLE_LANES
+  float* sum;           // [sum_lanes * npx][3] partial radiance sums per (lane, pixel), RGB side by side; sample s adds into lane s % JADE_SAMPLE_LANES
   // The context of a path in flight, four float4 = one aligned 64-B sector per record (only k_shade and a record k_light parks
   // touch it; what every pass of every record reads - rng, done, stage - is the header):
   //   {thr.xyz, obj} {acc.xyz, out.z} {le.xyz, src.x} {src.y, src.z, out.x, out.y}
@@ -240,11 +240,21 @@ struct DevCounters {  // three 64-B lines per shard; shade_tail adds by word ind
 
 // The per-(pixel, lane) partial sums: 3 planes of JADE_SAMPLE_LANES * npx floats — a full 4K frame on
 // one GPU is 3 x 2.1 G entries, past what an int index reaches, so these take 64-bit plane sizes.
-static __device__ __forceinline__ jvec3 ld3w(const float* a, size_t plane, size_t i) { return jv(a[i], a[plane + i], a[2 * plane + i]); }
+// Round 4: the three components of a sum sit side by side (12 B per (lane, pixel), index lane * npx + pixel), not in three planes.
+// k_shade adds a finished sample of a scattered record into ONE sector (now and then two) instead of three - read and written: it is
+// bound by the sectors it touches, and a tenth of them were these; the first pass, whose records are neighbours, streams either way.
+// (`plane` is what the plane layout needed; kept in the signature so that the call sites read as they did.)
+static __device__ __forceinline__ jvec3 ld3w(const float* a, size_t plane, size_t i) {
+  (void)plane;
+  const float* q = a + 3 * i;
+  return jv(q[0], q[1], q[2]);
+}
 static __device__ __forceinline__ void st3w(float* a, size_t plane, size_t i, jvec3 v) {
-  a[i] = v.x;
-  a[plane + i] = v.y;
-  a[2 * plane + i] = v.z;
+  (void)plane;
+  float* q = a + 3 * i;
+  q[0] = v.x;
+  q[1] = v.y;
+  q[2] = v.z;
 }
 static __device__ __forceinline__ jvec3 ld3(const float* a, int npix, int p) {
   return jv(a[p], a[npix + p], a[2 * npix + p]);

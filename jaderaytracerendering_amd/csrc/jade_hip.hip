@@ -3198,18 +3198,18 @@ static int advance(jade_scene* s, int64_t from0, bool may_carry, jade_stats* st)
 }
 
 // The steps add more samples than jade_render_begin was told of: more lanes of partial sums (jade_rt.h,
-// JADE_Q_SUM_LANES).  Lane l of plane c sits at (c * lanes + l) * npx, so the planes move apart; the new lanes are +0.
+// JADE_Q_SUM_LANES).
 static int grow_sums(jade_scene* s, int64_t spp_total) {
   PathState& P = s->ps;
   int lanes = P.sum_lanes;
   while (lanes < JADE_SAMPLE_LANES && lanes < spp_total) lanes <<= 1;
   if (lanes == P.sum_lanes) return JADE_OK;
   DevBuf nb;
-  const size_t plane_old = (size_t)P.sum_lanes * P.npx * 4, plane_new = (size_t)lanes * P.npx * 4;
-  HIP_TRY(nb.alloc(3 * plane_new));
-  HIP_TRY(hipMemsetAsync(nb.p, 0, 3 * plane_new, s->stream));
-  for (int c = 0; c < 3; ++c)
-    HIP_TRY(hipMemcpyAsync((char*)nb.p + c * plane_new, (const char*)s->b_sum.p + c * plane_old, plane_old, hipMemcpyDeviceToDevice, s->stream));
+  // (lane l of pixel p sits at (l * npx + p) * 3: more lanes are more of the same behind the old ones; the new lanes are +0)
+  const size_t bytes_old = (size_t)P.sum_lanes * P.npx * 12, bytes_new = (size_t)lanes * P.npx * 12;
+  HIP_TRY(nb.alloc(bytes_new));
+  HIP_TRY(hipMemsetAsync(nb.p, 0, bytes_new, s->stream));
+  HIP_TRY(hipMemcpyAsync(nb.p, s->b_sum.p, bytes_old, hipMemcpyDeviceToDevice, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
   std::swap(s->b_sum.p, nb.p);
   std::swap(s->b_sum.bytes, nb.bytes);
