@@ -171,6 +171,14 @@ struct PathState {
   // out, nslots results back) is one or two cache lines for k_shade - as planes (round 1) it was a line per component:
   // 28 lines per record and pass once the active list had thinned out.  A queue entry is the slot number p * nslots + k.
   float4* slot;
+  // Round 4: ONE float4 per slot - slot[p * nslots + k] = {direction, hit (int bits) / limit} - so that a record's rays are 16 B x
+  // nslots side by side (64 B, one sector, for the two-emitter scenes: k_shade read and wrote two), and ONE {hit point, distance} per
+  // record, hitp[p]: of a record's rays only the one whose nearest hit is wanted (the indirect ray, or the single ray of a mirror /
+  // refraction / camera stage - never two at once) gets a hit point; a yes/no query is answered with the triangle alone
+  // (JADE_WANTS_POINT), so k_trace neither solves for nor writes a point nobody reads.  write_all_hits (jade_trace_rays: one slot
+  // per "record"): every ray writes point and distance.
+  float4* hitp;
+  uint32_t write_all_hits;
   // jade_render_params.walk == JADE_WALK_EARLY_EXIT: k_trace ends a shadow / environment-visibility walk at the first recorded
   // hit that settles what k_shade asks of it.  The word a queued ray carries beside its direction (slot[..].w, overwritten by
   // the result) is the LIMIT as a float: the walk may end once its best distance is < limit.  -1 (a NaN: never) = the nearest

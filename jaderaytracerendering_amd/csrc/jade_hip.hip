@@ -227,7 +227,7 @@ static __device__ __forceinline__ void shade_record(const DevScene& S, const Pat
   const uint32_t word = hdr0.z;
   const uint32_t rng0 = hdr0.x;
   const uint32_t done0 = hdr0.y;
-  const float4 slot0 = P.slot[(size_t)pp * P.nslots * 2];  // slot 0: {direction, hit}
+  const float4 slot0 = P.slot[(size_t)pp * P.nslots];  // slot 0: {direction, hit}
   const int hit0 = __float_as_int(slot0.w);
   const jvec3 dir0 = jv(slot0.x, slot0.y, slot0.z);
   const uint32_t rec_m = (uint32_t)pp / (uint32_t)P.npx;
@@ -465,7 +465,7 @@ static __device__ __forceinline__ void shade_tail(const PathState& P, int p, uin
       ro = rskip == JADE_SKIP_CAMERA ? jv(P.eye[0], P.eye[1], P.eye[2]) : jv(og.x, og.y, og.z);
     }
     for (int k = 0; k < P.nslots; ++k) {
-      const float4* sl = P.slot + ((size_t)p * P.nslots + k) * 2;
+      const float4* sl = P.slot + ((size_t)p * P.nslots + k);
       const bool q = k < used && reinterpret_cast<const int*>(sl)[3] != -2;  // (-2: no ray in this slot; anything else: the queued ray's limit, jade_device.h)
       const unsigned long long m = __ballot(q);
       const uint32_t pos = wbase + (uint32_t)__popcll(m & below);
@@ -475,7 +475,7 @@ static __device__ __forceinline__ void shade_tail(const PathState& P, int p, uin
         const float4 dv = sl[0];
         jvec3 inv, dn;
         uint32_t skipx;
-        walk_prepare(ro, jv(dv.x, dv.y, dv.z), rskip, &inv, &dn, &skipx);
+        walk_prepare(ro, jv(dv.x, dv.y, dv.z), rskip, dv.w, &inv, &dn, &skipx);
         float4* rq = P.rayq + (size_t)pos * 3;
         nt_st4(rq, ro.x, ro.y, ro.z, __uint_as_float(skipx));
         nt_st4(rq + 1, inv.x, inv.y, inv.z, P.early_exit ? dv.w : __int_as_float(-1));
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(JADE_SHADE_BLOCK, JADE_SHADE_BIN_WAVES) void k_shad
   const int pp = p < npix ? p : 0;
   const uint4 hdr0 = P.hdr[pp];
   const uint32_t word = hdr0.z;
-  const float4 slot0 = P.slot[(size_t)pp * P.nslots * 2];
+  const float4 slot0 = P.slot[(size_t)pp * P.nslots];
   const int hit0 = __float_as_int(slot0.w);
   const jvec3 dir0 = jv(slot0.x, slot0.y, slot0.z);
   const uint32_t rec_m = (uint32_t)pp / (uint32_t)P.npx;
@@ -856,7 +856,7 @@ __global__ void k_ray_keys(PathState P, const uint32_t* queue, uint32_t n, uint3
   const uint32_t st = P.hdr[p].z & 255u;
   const float4 og = P.orgs[p];
   const int32_t skip = __float_as_int(og.w);
-  const float4 dv = P.slot[(size_t)e * 2];
+  const float4 dv = P.slot[(size_t)e];
   uint32_t cls = 7u;  // single-ray stages (mirror, refraction, camera)
   if (st == ST_DIFFUSE || st == ST_BSSRDF) cls = (int)k < n_emit ? (k < 5u ? k : 4u) : ((int)k == n_emit ? 5u : 6u);
   const uint32_t tri = skip < 0 ? 0u : ((uint32_t)skip & ((1u << tri_bits) - 1u));
@@ -1028,7 +1028,7 @@ static __device__ __forceinline__ void trace_body(const DevScene& S, const PathS
     uint32_t m_rays = 0;
     const int used = !tail_alive ? 0 : (st == ST_DIFFUSE || st == ST_BSSRDF) ? P.nslots : 1;
     for (int k = 0; k < P.nslots; ++k) {
-      const bool q = k < used && reinterpret_cast<const int*>(P.slot + ((size_t)tail_p * P.nslots + k) * 2)[3] != -2;
+      const bool q = k < used && reinterpret_cast<const int*>(P.slot + ((size_t)tail_p * P.nslots + k))[3] != -2;
       const unsigned long long m = __ballot(q);
       if (q) const_cast<uint32_t*>(queue)[m_rays + wt.rank_in(m)] = (uint32_t)tail_p * (uint32_t)P.nslots + (uint32_t)k;
       m_rays += (uint32_t)__popcll(m);
@@ -1055,7 +1055,7 @@ static __device__ __forceinline__ void trace_body(const DevScene& S, const PathS
         walk_restart(r, stk, S);
         r.skipx = (r.skipx & ~JADE_ATTEMPT) | (retry ? 0u : JADE_FORCE_BINARY);
         if (WIDE && lds_get(stk, TW_LIMIT) == JADE_LIMIT_TIE)  // (rare: the tie marker sits where the limit was - the ray's own comes back from its slot)
-          lds_putf(stk, TW_LIMIT, P.early_exit ? NT_LD(reinterpret_cast<const float*>(P.slot + (size_t)my_e * 2) + 3) : __int_as_float(-1));
+          lds_putf(stk, TW_LIMIT, P.early_exit ? NT_LD(reinterpret_cast<const float*>(P.slot + (size_t)my_e) + 3) : __int_as_float(-1));
       } else {
         active = false;
         wb = true;
@@ -1076,10 +1076,11 @@ static __device__ __forceinline__ void trace_body(const DevScene& S, const PathS
         float dist;
         jvec3 hp = jv(0, 0, 0);
         uint32_t parent1 = 0;
-        const int32_t best = walk_result(stk, S, r.od, &dist, &hp, &parent1);
-        float4* sl = P.slot + (size_t)my_e * 2;
-        NT_ST(reinterpret_cast<int32_t*>(sl) + 3, best);
-        nt_st4(sl + 1, hp.x, hp.y, hp.z, dist);  // (the hit point of a miss is never read; its distance stays INF, PathTrace.cu:799)
+        // (a yes/no query gets the triangle alone: nobody reads its hit point - jade_device.h, PathState.hitp)
+        const bool want_point = (r.skipx & JADE_WANTS_POINT) != 0u || P.write_all_hits != 0u;
+        const int32_t best = walk_result(stk, S, r.od, &dist, &hp, &parent1, want_point);
+        NT_ST(reinterpret_cast<int32_t*>(P.slot + (size_t)my_e) + 3, best);
+        if (want_point) nt_st4(P.hitp + (size_t)(my_e / (uint32_t)P.nslots), hp.x, hp.y, hp.z, dist);  // (the hit point of a miss is never read; its distance stays INF, PathTrace.cu:799)
         if (anyhit) {
           // occluder cache: an answer the cached subtrees gave is counted; one that took the whole walk leaves its leaf's parent
           // in one of the key's four ways (a plain store: entries are hints)
@@ -1141,7 +1142,7 @@ static __device__ __forceinline__ void trace_body(const DevScene& S, const PathS
           const float4 og = nt_ld4(&P.orgs[p]);
           const int32_t skip = __float_as_int(og.w);
           const jvec3 o = skip == JADE_SKIP_CAMERA ? jv(P.eye[0], P.eye[1], P.eye[2]) : jv(og.x, og.y, og.z);
-          const float4 dv = nt_ld4(&P.slot[(size_t)my_e * 2]);
+          const float4 dv = nt_ld4(&P.slot[(size_t)my_e]);
           const jvec3 d = jv(dv.x, dv.y, dv.z);
           // occluder cache (jade_trace.h): a yes/no query starts with the subtrees in which the last such queries from this
           // triangle found their answer - the lane's stack begins with them instead of the root.  (The entry is requested before
@@ -1149,7 +1150,7 @@ static __device__ __forceinline__ void trace_body(const DevScene& S, const PathS
           const bool anyq = anyhit && dv.w == dv.w && skip >= 0;
           uint4 c = make_uint4(0u, 0u, 0u, 0u);
           if (anyq) c = ld_anyhit(S.anyhit + (size_t)skip * JADE_ANYHIT_KEYS + anyhit_key(my_e - p * (uint32_t)P.nslots, (uint32_t)S.n_emit, d));
-          walk_begin(r, stk, S, o, d, skip, P.early_exit ? dv.w : __int_as_float(-1));
+          walk_begin(r, stk, S, o, d, skip, P.early_exit ? dv.w : __int_as_float(-1), dv.w);
           if (anyq && (int32_t)r.skipx >= 0) anyhit_seed(r, stk, c);  // (a ray with a non-finite 1/d takes the NaN-faithful walk from the root)
           active = true;
         }
@@ -2621,7 +2622,7 @@ static int setup_state(jade_scene* s, int npx, int rpp, int nslots, int sum_lane
   size_t words = 0;
   auto take = [&](size_t n) { size_t o = words; words += (n + 63) & ~(size_t)63; return o; };
   const size_t N = (size_t)npix, K = (size_t)nslots;
-  size_t o_hdr = take(4 * N), o_ctx = take(16 * N), o_aux = take(4 * N), o_orgs = take(4 * N), o_slot = take(8 * K * N);
+  size_t o_hdr = take(4 * N), o_ctx = take(16 * N), o_aux = take(4 * N), o_orgs = take(4 * N), o_slot = take(4 * K * N), o_hitp = take(4 * N);
   HIP_TRY(s->b_state.alloc(words * 4));
   HIP_TRY(hipMemsetAsync(s->b_state.p, 0, words * 4, s->stream));
   // the partial sums are an allocation of their own: they grow if steps add more samples than were announced (grow_sums)
@@ -2644,6 +2645,8 @@ static int setup_state(jade_scene* s, int npx, int rpp, int nslots, int sum_lane
   P.sum_lanes = sum_lanes;
   P.sum = s->b_sum.as<float>(); P.ctx = (float4*)(b + o_ctx); P.aux = (float4*)(b + o_aux); P.orgs = (float4*)(b + o_orgs);
   P.slot = (float4*)(b + o_slot);
+  P.hitp = (float4*)(b + o_hitp);
+  P.write_all_hits = 0u;
   HIP_TRY(s->b_queue.alloc(K * N * 4));
   // ray records for the head of the queue (PathState.rayq): as many as an eighth of all slots - a pass after the fused first one
   // queues rays for a few per cent of the records - but every slot of a small render; none when switched off
@@ -2695,7 +2698,7 @@ int jade_render_begin(jade_scene* s, const jade_render_params* rp) {
   // Records per pixel: as many paths in flight as JADE_RECORD_MEMORY of the free device memory holds (the
   // partial sums come out of the same share), whatever the image share of this GPU: more records = fewer,
   // wider passes.  288 GB is what makes 530 M paths (112 GB) for a full 1080p frame affordable.
-  const double bytes_per_record = 4.0 * (30 + 9 * nslots) + (s->tun.ray_records ? 6.0 * nslots : 0.0);  // PathState (a slot is two float4) + queue entry + two list entries + 48-B ray records for an eighth of the slots
+  const double bytes_per_record = 4.0 * (34 + 5 * nslots) + (s->tun.ray_records ? 6.0 * nslots : 0.0);  // PathState (a float4 per slot, one hit point per record) + queue entry + two list entries + 48-B ray records for an eighth of the slots
   // partial sums per pixel: one lane per sample up to JADE_SAMPLE_LANES, never more than the render was announced with
   // (rounded up to a power of two): a 1-spp 4K frame is 100 MB of sums, not 102 GB
   int sum_lanes = JADE_SAMPLE_LANES;
@@ -3472,7 +3475,7 @@ static int trace_rays_impl(jade_scene* s, int32_t n, const float* origins, const
   HIP_TRY(hipSetDevice(s->device));
   // a throw-away PathState with one slot per "pixel"
   const size_t N = (size_t)n;
-  std::vector<float4> so(N), sl(2 * N);
+  std::vector<float4> so(N), sl(N), hp(N, make_float4(0.0f, 0.0f, 0.0f, 0.0f));  // (the hit point of a miss is reported as zeros)
   for (size_t i = 0; i < N; ++i) {
     const int32_t sk = skip[i] < 0 ? -1 : skip[i];  // any negative value means "no source triangle" (the device keeps -2 for camera rays)
     float skf, qf;
@@ -3480,14 +3483,14 @@ static int trace_rays_impl(jade_scene* s, int32_t n, const float* origins, const
     memcpy(&skf, &sk, 4);
     memcpy(&qf, &queued, 4);
     so[i] = make_float4(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2], skf);
-    sl[2 * i] = make_float4(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], limits ? limits[i] : qf);
-    sl[2 * i + 1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // the hit point of a miss is reported as zeros
+    sl[i] = make_float4(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], limits ? limits[i] : qf);
   }
   std::vector<uint32_t> q(N);
   for (size_t i = 0; i < N; ++i) q[i] = (uint32_t)i;
-  DevBuf b_orgs, b_slot, b_q, b_spill;
+  DevBuf b_orgs, b_slot, b_hitp, b_q, b_spill;
   HIP_TRY(upload(b_orgs, so.data(), so.size(), s->stream));
   HIP_TRY(upload(b_slot, sl.data(), sl.size(), s->stream));
+  HIP_TRY(upload(b_hitp, hp.data(), hp.size(), s->stream));
   HIP_TRY(upload(b_q, q.data(), N, s->stream));
   HIP_TRY(b_spill.alloc((size_t)(JADE_BVH_STACK_CAPACITY - JADE_LDS_STACK) * s->trace_blocks * JADE_TRACE_BLOCK * 4));
   PathState P{};
@@ -3495,6 +3498,8 @@ static int trace_rays_impl(jade_scene* s, int32_t n, const float* origins, const
   P.nslots = 1;
   P.orgs = b_orgs.as<float4>();
   P.slot = b_slot.as<float4>();
+  P.hitp = b_hitp.as<float4>();
+  P.write_all_hits = 1u;  // (this entry point reports point and distance of EVERY ray, also of one that carries a yes/no limit)
   P.early_exit = limits ? (cached ? 2u : 1u) : 0u;
   // everything on the scene's own (non-blocking) stream: the null stream does not order against it
   QueueCtl qc{};
@@ -3513,16 +3518,17 @@ static int trace_rays_impl(jade_scene* s, int32_t n, const float* origins, const
   float ms = 0;
   HIP_TRY(hipEventElapsedTime(&ms, ev0.e, ev1.e));
   // HitResult.distance (PathTrace.cu:740) exactly as the kernel compared it (hitArray's `<`, :787); a miss keeps INF (:799)
-  HIP_TRY(hipMemcpyAsync(sl.data(), b_slot.p, 2 * N * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipMemcpyAsync(sl.data(), b_slot.p, N * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipMemcpyAsync(hp.data(), b_hitp.p, N * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
   for (size_t i = 0; i < N; ++i) {
-    memcpy(&hit_index[i], &sl[2 * i].w, 4);
-    if (hit_dist) hit_dist[i] = sl[2 * i + 1].w;
+    memcpy(&hit_index[i], &sl[i].w, 4);
+    if (hit_dist) hit_dist[i] = hp[i].w;
     if (hit_point) {
       const bool hit = hit_index[i] >= 0;
-      hit_point[3 * i] = hit ? sl[2 * i + 1].x : 0.0f;
-      hit_point[3 * i + 1] = hit ? sl[2 * i + 1].y : 0.0f;
-      hit_point[3 * i + 2] = hit ? sl[2 * i + 1].z : 0.0f;
+      hit_point[3 * i] = hit ? hp[i].x : 0.0f;
+      hit_point[3 * i + 1] = hit ? hp[i].y : 0.0f;
+      hit_point[3 * i + 2] = hit ? hp[i].z : 0.0f;
     }
   }
   if (st) {

@@ -169,8 +169,8 @@ struct Px {
   const PathState& P;
   int p;
   __device__ Px(const PathState& ps, int pix) : P(ps), p(pix) {}
-  // the record's ray slots: two float4 per slot, side by side per record (jade_device.h)
-  __device__ float4* slot(int k) const { return P.slot + ((size_t)p * P.nslots + k) * 2; }
+  // the record's ray slots: one float4 per slot, side by side per record; one hit point per record (jade_device.h)
+  __device__ float4* slot(int k) const { return P.slot + ((size_t)p * P.nslots + k); }
   __device__ jvec3 dir(int k) const {
     const float4 v = slot(k)[0];
     return jv(v.x, v.y, v.z);
@@ -179,8 +179,9 @@ struct Px {
     float* f = reinterpret_cast<float*>(slot(k));
     f[0] = v.x; f[1] = v.y; f[2] = v.z;
   }
-  __device__ jvec3 hpt(int k) const {
-    const float4 v = slot(k)[1];
+  __device__ jvec3 hpt(int k) const {  // (k: the slot of the record's one ray whose nearest hit was wanted - the caller knows which)
+    (void)k;
+    const float4 v = P.hitp[p];
     return jv(v.x, v.y, v.z);
   }
   __device__ int hit(int k) const { return reinterpret_cast<const int*>(slot(k))[3]; }

@@ -749,7 +749,8 @@ static_assert((JADE_HQ & (JADE_HQ - 1)) == 0 && JADE_HQ >= 128, "JADE_HQ");
 #define JADE_CUT 0x40000000u          /* WalkState.skipx: the ray has its answer (early exit) */
 #define JADE_FORCE_BINARY 0x20000000u /* ... this ray takes binary units only (it is being walked again after a tie, "Wide walk") */
 #define JADE_ATTEMPT 0x10000000u      /* ... the walk in progress covers the cached subtrees only ("Occluder cache" below): without an answer the whole walk follows */
-#define JADE_SKIP_MASK 0x0fffffffu    /* ... its source triangle (all ones = none; triangle indices stay below 2^27 / 3) */
+#define JADE_WANTS_POINT 0x08000000u  /* ... the caller wants the nearest hit itself - triangle, hit point, distance (its limit is a NaN); a yes/no query gets the triangle alone */
+#define JADE_SKIP_MASK 0x03ffffffu    /* ... its source triangle (all ones = none; triangle indices stay below 2^27 / 3 < 2^26) */
 
 // ---------------------------------------------------------------------------------------------------------------
 // Occluder cache (round 4; jade_render_params.walk == JADE_WALK_EARLY_EXIT_CACHED).  A shadow or environment-visibility query only
@@ -788,14 +789,16 @@ static __device__ __forceinline__ uint32_t lds_ld_v(uint32_t addr) { return *(vo
 
 // limit: the walk may end as soon as the ray's best distance is < limit (jade_device.h, PathState.early_exit; a NaN = never:
 // the nearest hit is wanted and the walk is the reference's)
-static __device__ __forceinline__ void walk_begin(WalkState& r, const LdsStack& stk, const DevScene& S, jvec3 o, jvec3 d, int32_t skip, float limit) {
+// query_limit: the limit word the caller put beside the ray, whatever the walk mode - a NaN there means "the nearest hit itself is
+// wanted" (JADE_WANTS_POINT); `limit` is what may end the walk early (a NaN in the reference's walk mode for every ray)
+static __device__ __forceinline__ void walk_begin(WalkState& r, const LdsStack& stk, const DevScene& S, jvec3 o, jvec3 d, int32_t skip, float limit, float query_limit) {
   const jvec3 inv = jv(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
   const jvec3 dn = jv_normalize(d);
   r.od.a = f2{o.x, o.y};
   r.od.b = f2{o.z, dn.x};
   r.od.c = f2{dn.y, dn.z};
   const bool exact = !(finite_f(inv.x) && finite_f(inv.y) && finite_f(inv.z)) || !finite_f(o.x) || !finite_f(o.y) || !finite_f(o.z);
-  r.skipx = (skip < 0 ? JADE_SKIP_MASK : (uint32_t)skip) | (exact ? 0x80000000u : 0u);
+  r.skipx = (skip < 0 ? JADE_SKIP_MASK : (uint32_t)skip) | (exact ? 0x80000000u : 0u) | (query_limit == query_limit ? 0u : JADE_WANTS_POINT);
   r.sp = stk.col;
   r.pushed = 0;
   r.cur = S.root_ref;
@@ -810,11 +813,11 @@ static __device__ __forceinline__ void walk_begin(WalkState& r, const LdsStack& 
 #endif
 }
 // walk_begin's arithmetic on its own - what a ray record carries (jade_device.h, PathState.rayq): 1 / d, normalize(d) and the skip word
-static __device__ __forceinline__ void walk_prepare(jvec3 o, jvec3 d, int32_t skip, jvec3* inv_out, jvec3* dn_out, uint32_t* skipx_out) {
+static __device__ __forceinline__ void walk_prepare(jvec3 o, jvec3 d, int32_t skip, float limit, jvec3* inv_out, jvec3* dn_out, uint32_t* skipx_out) {
   const jvec3 inv = jv(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
   *dn_out = jv_normalize(d);
   const bool exact = !(finite_f(inv.x) && finite_f(inv.y) && finite_f(inv.z)) || !finite_f(o.x) || !finite_f(o.y) || !finite_f(o.z);
-  *skipx_out = (skip < 0 ? JADE_SKIP_MASK : (uint32_t)skip) | (exact ? 0x80000000u : 0u);
+  *skipx_out = (skip < 0 ? JADE_SKIP_MASK : (uint32_t)skip) | (exact ? 0x80000000u : 0u) | (limit == limit ? 0u : JADE_WANTS_POINT);
   *inv_out = inv;
 }
 // ... and walk_begin from such a record
@@ -932,15 +935,19 @@ static __device__ __forceinline__ void resolve_hit(uint32_t ref, uint32_t meta, 
 }
 // The hit a finished ray reports: triangle index (-1 = miss), distance and hit point of the winning triangle.
 // parent1: the winning triangle's leaf's parent + 1 (the pair record's flag word, bits 1-31; 0 = none, or no hit)
-static __device__ __forceinline__ int32_t walk_result(const LdsStack& stk, const DevScene& S, const RayOD& od, float* dist, jvec3* P, uint32_t* parent1 = nullptr) {
+// want_point = false: a yes/no query - the triangle alone (one 16-B word of the record instead of the whole solve)
+static __device__ __forceinline__ int32_t walk_result(const LdsStack& stk, const DevScene& S, const RayOD& od, float* dist, jvec3* P, uint32_t* parent1 = nullptr,
+                                                      bool want_point = true) {
   const uint32_t ref = lds_get(stk, TW_BEST_REF);
   *dist = lds_getf(stk, TW_BEST_DIST);
   if (parent1) *parent1 = 0u;
   if (ref == 0xffffffffu) return -1;
   const float4* t0 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.tverts) + (ref & 0x7ffffff0u));
   const int k = (int)(ref & 1u);
-  float d2;
-  pair_hit(t0, k, od, &d2, P);
+  if (want_point) {
+    float d2;
+    pair_hit(t0, k, od, &d2, P);
+  }
   const float4 tag = t0[4];
   if (parent1) *parent1 = jade_f2u(tag.w) >> 1;
   return (int32_t)(jade_f2u(tag.z) + (uint32_t)k);
