@@ -58,8 +58,12 @@ $(LIBDIR)/jade_render: $(PKG)/host/jade_render_cli.cpp $(LIBDIR)/libjade_host.so
 	$(CXX) $(CXXFLAGS) -o $@ $(PKG)/host/jade_render_cli.cpp -L$(LIBDIR) -ljade_host -ldl -Wl,-rpath,'$$ORIGIN'
 
 # FETCH_SIZE / TCC_* calibration on k_trace's access pattern (tools/calib/fetch_calib.hip; run under rocprofv3 --pmc)
-calib: $(LIBDIR)/fetch_calib
+# VALU issue calibration (tools/calib/valu_calib.hip): wave64 instructions per SIMD per clock, by instruction kind and occupancy
+calib: $(LIBDIR)/fetch_calib $(LIBDIR)/valu_calib
 $(LIBDIR)/fetch_calib: $(ROOT)/tools/calib/fetch_calib.hip
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) -O3 -std=c++17 --offload-arch=gfx950 -o $@ $<
+$(LIBDIR)/valu_calib: $(ROOT)/tools/calib/valu_calib.hip
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) -O3 -std=c++17 --offload-arch=gfx950 -o $@ $<
 

@@ -30,8 +30,12 @@ static __device__ jvec3 sample_hdr(const DevScene& S, jvec3 v) {
   jvec3 nv = jv_normalize(v);
   float ux = jade_atan2f(nv.z, nv.x);
   float uy = jade_asinf(nv.y);
-  ux = (float)((double)ux / (2.0 * JADE_PI_D));
-  uy = (float)((double)uy / JADE_PI_D);
+  // (float)((double)x / C) written as (float)((double)x * (1.0 / C)): NOT the same in general, but the same for EVERY float |x| <= 3.2
+  // with C = 2 * JADE_PI_D and |x| <= 1.6 with C = JADE_PI_D - all 4.3e9 of them compared (tests/native/dpdiv_exhaustive.c,
+  // tests/test_fpmath.py) - and atan2 / asin return nothing outside those ranges.  Two double-precision divisions (~15 instructions
+  // each at half rate or less) become two multiplications in a function every sky sample of the first pass runs.
+  ux = (float)((double)ux * (1.0 / (2.0 * JADE_PI_D)));
+  uy = (float)((double)uy * (1.0 / JADE_PI_D));
   ux = (float)((double)ux + 0.5);
   uy = (float)((double)uy + 0.5);
   uy = (float)(1.0 - (double)uy);

@@ -144,3 +144,29 @@ def test_double_rounding_is_innocuous_for_division():
     assert np.array_equal((x.astype(np.float64) / 3.0).astype(np.float32), x / np.float32(3.0))
     u = rng.random(500000).astype(np.float32)
     assert np.array_equal((2.0 * (u.astype(np.float64) - 0.5)).astype(np.float32), np.float32(2.0) * (u - np.float32(0.5)))
+
+
+def test_division_by_pi_in_double_equals_multiplication_for_every_float_in_range(fpm, tmp_path):
+    """jade_shade.h's sample_hdr computes (float)((double)x * (1.0 / C)) where PathTrace.cu:689-690 (and the oracle) compute
+    (float)((double)x / C), C = 2 pi and pi (the reference's 3.1415926).  In general the two differ; for the values atan2 and asin can
+    return they do not - checked here for EVERY float |x| <= 3.2 (C = 2 pi) and |x| <= 1.6 (C = pi), 4.3e9 inputs, and the ranges
+    of this repo's own atan2 / asin are checked against those bounds."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "dpdiv")
+    subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-ffp-contract=off", "-fno-fast-math", "-I", os.path.join(ROOT, "include"), "-o", exe,
+                           os.path.join(ROOT, "tests", "native", "dpdiv_exhaustive.c")])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout
+    rows = [line.split() for line in out.stdout.splitlines()]
+    assert len(rows) == 2 and all(int(r[3]) == 0 and int(r[2]) > 2 * 10 ** 9 for r in rows), rows
+    # the ranges: atan2 over directions of every kind, asin over [-1, 1] (and slightly beyond: NaN, which is tested for separately)
+    rng = np.random.default_rng(3)
+    y = np.concatenate([rng.normal(size=200000), [0.0, -0.0, 1e-30, -1e-30, 1.0, -1.0]]).astype(np.float32)
+    x = np.concatenate([rng.normal(size=200000), [-1.0, -1.0, -1.0, -1.0, 0.0, -0.0]]).astype(np.float32)
+    a = np.empty_like(x)
+    fpm.t_atan2(y.ctypes.data_as(ctypes.c_void_p), x.ctypes.data_as(ctypes.c_void_p), a.ctypes.data_as(ctypes.c_void_p), len(x))
+    assert np.nanmax(np.abs(a)) <= 3.2
+    s = _call1(fpm.t_asin, np.linspace(-1, 1, 400001).astype(np.float32))
+    assert np.nanmax(np.abs(s)) <= 1.6
