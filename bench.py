@@ -61,6 +61,10 @@ L2_GATHER_PEAK_GBS = 16800.0               # MI355X_MICROARCH.md, "Indexed rows"
 # its instruction count; the final one issues a third fewer instructions and sits at 0.7.  The roofline below
 # is priced against the full 2-clock rate, `issue_busy_of_2` says how far the issue side is from it.
 VALU_PEAK_TLANEOPS = 1024 * 32 * 2.4e9 / 1e12  # 256 CUs x 4 SIMDs x 32 lanes, 2.4 GHz = 78.6 T lane-ops/s
+# The issue roof of the instruction kinds k_trace is made of (min / max, compare, select, integer, packed fp32): ONE wave64 instruction
+# per SIMD per 4 clocks at any occupancy - measured, profiles/valu_calibration.json (tools/calib/valu_calib.hip); only unpacked fp32
+# add / mul / fma and v_mov_b32 issue at up to one per 2 clocks, which is what the lane-operation peak above assumes of every instruction
+VALU_ISSUE_PEAK_GINST = 1024 * 0.25 * 2.4e9 / 1e9  # 614 G wave-instructions/s
 
 
 def parse():
@@ -360,6 +364,12 @@ def main():
                              "frac_of_one_instruction_per_4_clocks": None,
                              "note": "peak = one wave64 VALU instruction per SIMD per 2 clocks (MI355X_MICROARCH.md: 2 cycles on a SIMD-32, which "
                                      "takes two or more waves per SIMD; ONE wave's own stream issues one per 4); issue_busy_of_2 = 4 x SQ_ACTIVE_INST_VALU / SIMD-cycles"}),
+            "valu_issue": roof_of("valu_issue", c.get("valu_wave_insts_per_ray"), 1e9, VALU_ISSUE_PEAK_GINST, "Ginst/s",
+                                  {"valu_wave_insts_per_ray": c.get("valu_wave_insts_per_ray"), "valu_busy_profiled": c.get("valu_busy"),
+                                   "note": "wave64 VALU instructions issued per second against one per SIMD per 4 clocks: the calibrated issue rate of every "
+                                           "instruction kind but unpacked fp32 add / mul / fma and v_mov (profiles/valu_calibration.json); idle lanes are "
+                                           "not counted against the kernel here (they are in the 'valu' roof's lane-operations).  valu_busy_profiled = 4 x "
+                                           "instructions per SIMD per clock over the profiled run's own clocks"}),
             "l2": roof_of("l2", (c.get("l2_requests_per_ray") or 0) * 64.0, 1e9, L2_GATHER_PEAK_GBS, "GB/s",
                           {"l2_requests_per_ray": c.get("l2_requests_per_ray"), "l2_hit_rate": c.get("l2_hit_rate"),
                            "note": "(TCC_HIT_sum + TCC_MISS_sum) x 64 B per ray; peak = what the guide measures for gathers served by the XCDs' L2s (16.8-18.8 TB/s)"}),

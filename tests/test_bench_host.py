@@ -28,6 +28,23 @@ def test_counter_file_belongs_to_the_tree():
         assert e["valu_lane_ops_per_ray"] > 0 and e["l2_requests_per_ray"] > 0 and e["hbm_bytes_per_ray"] > 0 and e["fetch_size_factor"] == 1.0
 
 
+def test_issue_roof_is_the_calibrated_one():
+    """bench.py's `valu_issue` roof (one wave64 instruction per SIMD per 4 clocks) is a measurement, not a reading of the guide:
+    profiles/valu_calibration.json holds tools/calib/valu_calib's runs - every instruction kind but unpacked fp32 add / mul / fma and
+    v_mov stays at 0.25 per clock from 2 waves per SIMD up, those four reach nearly twice that."""
+    cal = json.load(open(os.path.join(ROOT, "profiles", "valu_calibration.json")))
+    assert abs(cal["single_rate_insts_per_simd_per_clock_5_waves"] - 0.25) < 0.01
+    assert abs(bench.VALU_ISSUE_PEAK_GINST - 1024 * 0.25 * 2.4) < 1e-9
+    by = {(r["kernel"], r["waves_per_simd"]): r for r in cal["runs"]}
+    for kind in ("v_pk_fma_f32", "v_pk_add_f32", "v_max3_f32", "v_cmp_lt_f32+v_cndmask_b32", "v_min_f32+v_cndmask_b32+v_add_u32+v_max_f32"):
+        for w in (2, 5, 8):
+            assert 0.21 < by[(kind, w)]["wave_insts_per_simd_per_busy_clock"] < 0.27, (kind, w)
+    for kind in ("v_fma_f32", "v_add_f32", "v_mul_f32", "v_mov_b32"):
+        assert by[(kind, 8)]["wave_insts_per_simd_per_busy_clock"] > 0.45, kind
+    # valu_busy (tools/summarize_prof.py) is 4 x instructions per SIMD per clock: 1.0 at this roof
+    assert all(abs(r["valu_busy"] - 4 * r["wave_insts_per_simd_per_busy_clock"]) < 0.01 for r in cal["runs"])
+
+
 # ---- the two ways bench.py is started on more than one GPU (VERDICT r3 item 1) -----------------------------------------------
 # The driver starts it under `python -m torch.distributed.run` (one rank per GPU) and sets nothing in the environment; started by
 # hand with --gpus N it spawns that launcher itself.  Either way every rank must (a) have HSA_ENABLE_IPC_MODE_LEGACY=0 in its

@@ -39,7 +39,7 @@ def test_bench_json_contract():
     # three roofs for the dominant kernel (VALU lane-ops, L2 requests, HBM bytes); `roofline` is the binding one.  The per-ray
     # counter figures exist for the profiled configurations (C3 / C5 at their own frame size) and for the build they were
     # cut from only, so a tiny run carries the live quantities and null for the rest
-    assert set(rs) == {"valu", "l2", "hbm"} and rf["bound"] in rs and rf["kernel"] == "k_trace"
+    assert set(rs) == {"valu", "valu_issue", "l2", "hbm"} and rf["bound"] in rs and rf["kernel"] == "k_trace"
     assert rs["valu"]["unit"] == "Tlane-op/s" and abs(rs["valu"]["peak"] - 78.6432) < 1e-6
     assert rs["l2"]["unit"] == "GB/s" and rs["l2"]["peak"] == 16800.0 and rs["hbm"]["peak"] == 8000.0
     assert rf["launches"] >= 1 and rf["avg_launch_ms"] > 0 and rf["achieved"] is None and rf["frac"] is None and d["binding"] is None
