@@ -180,13 +180,23 @@ static __device__ __forceinline__ f2 f2fma(f2 a, f2 b, f2 c) { return __builtin_
 // slab values.  `exact` selects the NaN-faithful ternary form; it is only needed when a
 // component of 1/dir or of the origin is not finite (0 * inf is the one way a NaN can appear
 // for a finite scene), otherwise v_min/v_max give bit-identical slab values.
-static __device__ __forceinline__ float slab_reduce(float fx, float fy, float fz, float nx, float ny, float nz, bool exact) {
+// What the walk needs of the returned value r = (t1 >= t0) ? ((t0 > 0) ? t0 : t1) : -1 (:769-770) is "r > 0" - the box is met - and, where
+// two boxes are met, which r is smaller.  r > 0  <=>  t1 >= t0 and t1 > 0: with t1 >= t0 (neither is a NaN then), t0 > 0 gives r = t0 > 0 and
+// t1 >= t0 > 0; t0 <= 0 gives r = t1.  So a box costs two comparisons (and a scalar `and`), and r itself - a comparison and a select more -
+// is formed only by the binary unit, for the order of two boxes both met (slab_dist).  Everything issues at one per 4 clocks
+// (profiles/valu_calibration.json): per node visit 11 -> 9 such instructions, per packet visit 11 -> 4, per wide unit 20 -> 8.
+struct Slab {
   float t0, t1;
+};
+static __device__ __forceinline__ bool slab_met(const Slab& s) { return (s.t1 >= s.t0) & (s.t1 > 0.0f); }
+static __device__ __forceinline__ float slab_dist(const Slab& s) { return (s.t0 > 0.0f) ? s.t0 : s.t1; }  // r of a box that is met
+static __device__ __forceinline__ Slab slab_reduce(float fx, float fy, float fz, float nx, float ny, float nz, bool exact) {
+  Slab s;
   if (exact) {
     float tmaxx = fx > nx ? fx : nx, tmaxy = fy > ny ? fy : ny, tmaxz = fz > nz ? fz : nz;
     float tminx = fx < nx ? fx : nx, tminy = fy < ny ? fy : ny, tminz = fz < nz ? fz : nz;
-    t1 = jade_fminf(tmaxx, jade_fminf(tmaxy, tmaxz));
-    t0 = jade_fmaxf(tminx, jade_fmaxf(tminy, tminz));
+    s.t1 = jade_fminf(tmaxx, jade_fminf(tmaxy, tmaxz));
+    s.t0 = jade_fmaxf(tminx, jade_fmaxf(tminy, tminz));
   } else {
     // no NaN can occur here, so plain v_max/v_min ARE the ternaries; spelled as instructions
     // because the builtins make the compiler quiet each operand first (six extra v_max x,x,x)
@@ -197,18 +207,18 @@ static __device__ __forceinline__ float slab_reduce(float fx, float fy, float fz
     asm("v_min_f32_e32 %0, %1, %2" : "=v"(lx) : "v"(fx), "v"(nx));
     asm("v_min_f32_e32 %0, %1, %2" : "=v"(ly) : "v"(fy), "v"(ny));
     asm("v_min_f32_e32 %0, %1, %2" : "=v"(lz) : "v"(fz), "v"(nz));
-    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(t1) : "v"(hx), "v"(hy), "v"(hz));
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t0) : "v"(lx), "v"(ly), "v"(lz));
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(s.t1) : "v"(hx), "v"(hy), "v"(hz));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(s.t0) : "v"(lx), "v"(ly), "v"(lz));
   }
-  return (t1 >= t0) ? ((t0 > 0.0f) ? t0 : t1) : -1.0f;
+  return s;
 }
 // both children of a node record (jade_device.h): lane .x = left box, .y = right box
-static __device__ __forceinline__ void slab2(const RayOD& od, jvec3 inv, float4 q0, float4 q1, float4 q2, bool exact, float* d1, float* d2) {
+static __device__ __forceinline__ void slab2(const RayOD& od, jvec3 inv, float4 q0, float4 q1, float4 q2, bool exact, Slab* s1, Slab* s2) {
   const f2 ax = {q0.x, q0.y}, ay = {q0.z, q0.w}, az = {q1.x, q1.y}, bx = {q1.z, q1.w}, by = {q2.x, q2.y}, bz = {q2.z, q2.w};
   const f2 fx = (bx - OD_OX(od)) * f2s(inv.x), fy = (by - OD_OY(od)) * f2s(inv.y), fz = (bz - OD_OZ(od)) * f2s(inv.z);
   const f2 nx = (ax - OD_OX(od)) * f2s(inv.x), ny = (ay - OD_OY(od)) * f2s(inv.y), nz = (az - OD_OZ(od)) * f2s(inv.z);
-  *d1 = slab_reduce(fx.x, fy.x, fz.x, nx.x, ny.x, nz.x, exact);
-  *d2 = slab_reduce(fx.y, fy.y, fz.y, nx.y, ny.y, nz.y, exact);
+  *s1 = slab_reduce(fx.x, fy.x, fz.x, nx.x, ny.x, nz.x, exact);
+  *s2 = slab_reduce(fx.y, fy.y, fz.y, nx.y, ny.y, nz.y, exact);
 }
 
 static __device__ __forceinline__ bool finite_f(float x) { return (jade_f2u(x) & 0x7f800000u) != 0x7f800000u; }
@@ -379,30 +389,30 @@ static __device__ __forceinline__ uint32_t node_decide(const NodeRec& nr, uint32
   const uint2 rf = nr.rf;
   // 1/d: from the caller's registers (k_trace, which has them to spare at 4 waves per SIMD) or from the lane's column
   const jvec3 inv = inv_reg ? *inv_reg : jv(lds_getf(stk, W_INV), lds_getf(stk, W_INV + 1), lds_getf(stk, W_INV + 2));
-  float d1, d2;
+  Slab s1, s2;
 #if JADE_ABLATE_SLAB
   {
     RayOD o2 = od;
     o2.a.x += 1e-30f;
-    float e1, e2;
+    Slab e1, e2;
     slab2(o2, inv, a, b, c, GENERAL, &e1, &e2);
-    asm volatile("" ::"v"(e1 + e2));
+    asm volatile("" ::"v"(e1.t0 + e2.t0 + e1.t1 + e2.t1));
   }
 #endif
-  slab2(od, inv, a, b, c, GENERAL, &d1, &d2);
+  slab2(od, inv, a, b, c, GENERAL, &s1, &s2);
   bool in1, in2;
   if (GENERAL) {
     const bool c1 = !is_leaf && rf.x != JADE_REF_NONE, c2 = !is_leaf && rf.y != JADE_REF_NONE;  // a missing child is neither counted nor entered
     vcnt += (c1 ? 1u : 0u) + (c2 ? 1u : 0u);
-    in1 = c1 && d1 > 0;
-    in2 = c2 && d2 > 0;
+    in1 = c1 && slab_met(s1);
+    in2 = c2 && slab_met(s2);
   } else {
     vcnt += is_leaf ? 0u : 2u;
-    in1 = !is_leaf && d1 > 0;
-    in2 = !is_leaf && d2 > 0;
+    in1 = !is_leaf && slab_met(s1);
+    in2 = !is_leaf && slab_met(s2);
   }
   const bool both = in1 && in2, any = in1 || in2;
-  const bool first = d1 < d2;  // near child first, PathTrace.cu:835-848
+  const bool first = slab_dist(s1) < slab_dist(s2);  // near child first, PathTrace.cu:835-848 (looked at only where both are met)
   const uint32_t near = both ? (first ? rf.x : rf.y) : (in1 ? rf.x : rf.y);
   const uint32_t far = first ? rf.y : rf.x;
   const bool near_leaf_ok = any && (int32_t)near < 0 && room;  // the near leaf is met now
@@ -491,14 +501,15 @@ static __device__ __forceinline__ uint32_t node_decide4(const NodeRec4& nr, uint
                                                         uint32_t& vcnt, const jvec3& inv) {
   const uint32_t cur = cur_io;
   const bool is_leaf = (int32_t)cur < 0;
-  float d0, d1, d2, d3;
-  slab2(od, inv, nr.a0, nr.b0, nr.c0, false, &d0, &d1);
-  slab2(od, inv, nr.a1, nr.b1, nr.c1, false, &d2, &d3);
+  Slab b0, b1, b2, b3;
+  slab2(od, inv, nr.a0, nr.b0, nr.c0, false, &b0, &b1);
+  slab2(od, inv, nr.a1, nr.b1, nr.c1, false, &b2, &b3);
   const uint4 rf = nr.rf;
   const bool v1 = rf.y != JADE_REF_NONE, v3 = rf.w != JADE_REF_NONE;  // (slots 0 and 2 always hold a child)
   vcnt += is_leaf ? 0u : 2u + (v1 ? 1u : 0u) + (v3 ? 1u : 0u);
-  const bool in0 = !is_leaf && d0 > 0, in1 = !is_leaf && v1 && d1 > 0, in2 = !is_leaf && d2 > 0, in3 = !is_leaf && v3 && d3 > 0;
+  const bool in0 = !is_leaf && slab_met(b0), in1 = !is_leaf && v1 && slab_met(b1), in2 = !is_leaf && slab_met(b2), in3 = !is_leaf && v3 && slab_met(b3);
 #if JADE_WIDE_ORDERED
+  const float d0 = slab_dist(b0), d1 = slab_dist(b1), d2 = slab_dist(b2), d3 = slab_dist(b3);  // (compared only where both boxes are met)
   // the nearest of the boxes met is next; of the others, the pair it does not belong to goes onto the stack first (it comes off
   // last), its sibling last
   // (decisions as and / or of lane masks: a `?:` between two of them is materialised in a register and compared again)
@@ -1321,18 +1332,18 @@ static __device__ __forceinline__ bool packet_trace(const DevScene& S, uint32_t 
       jade_const_f4* nd = as_const_f4(S.nodes, cur * 64u);
       const float4 a = ld_const_f4(nd), b = ld_const_f4(nd + 1), c = ld_const_f4(nd + 2), r4 = ld_const_f4(nd + 3);
       const uint32_t left = jade_f2u(r4.x), right = jade_f2u(r4.y);
-      float d1, d2;
-      slab2(od, inv, a, b, c, GENERAL, &d1, &d2);
+      Slab s1, s2;
+      slab2(od, inv, a, b, c, GENERAL, &s1, &s2);
       bool in1, in2;
       if (GENERAL) {
         const bool c1 = left != JADE_REF_NONE, c2 = right != JADE_REF_NONE;  // a missing child is neither counted nor entered
         if (in) vcnt += (c1 ? 1u : 0u) + (c2 ? 1u : 0u);
-        in1 = in && c1 && d1 > 0;
-        in2 = in && c2 && d2 > 0;
+        in1 = in && c1 && slab_met(s1);
+        in2 = in && c2 && slab_met(s2);
       } else {
         if (in) vcnt += 2u;
-        in1 = in && d1 > 0;
-        in2 = in && d2 > 0;
+        in1 = in && slab_met(s1);
+        in2 = in && slab_met(s2);
       }
       const unsigned long long m1 = __ballot(in1), m2 = __ballot(in2);
       if (m1 != 0ull) {
