@@ -72,7 +72,17 @@ def _ranks(cmd, extra_env=None):
         cmd[cmd.index("--master-port") + 1] = str(_free_port())
         out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
-    recs = [json.loads(line) for line in out.stdout.splitlines() if line.startswith("{")]
+    # (the ranks share one stdout: two of them may print into the same line - scan for objects rather than for lines)
+    recs, dec, text, at = [], json.JSONDecoder(), out.stdout, 0
+    while (at := text.find("{", at)) >= 0:
+        try:
+            obj, end = dec.raw_decode(text, at)
+        except json.JSONDecodeError:
+            at += 1
+            continue
+        at = end
+        if isinstance(obj, dict) and "rank" in obj:
+            recs.append(obj)
     return sorted(recs, key=lambda r: r["rank"])
 
 
