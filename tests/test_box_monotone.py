@@ -64,3 +64,22 @@ def test_a_ray_that_meets_a_box_meets_its_parents(oracle, name):
             assert st.nodes_visited == 1 + 2 * int(entered[1:].sum() if cnt[1] == 0 else 0) or cnt[1] > 0
             met_total += int(met[kids].sum())
     assert met_total > 1000
+
+
+def test_met_rule_equals_the_returned_value_being_positive():
+    """jade_trace.h asks of hitAABB's value r = (t1 >= t0) ? ((t0 > 0) ? t0 : t1) : -1 (PathTrace.cu:769-770) only "r > 0", as
+    `t1 >= t0 && t1 > 0` (slab_met), and forms r = (t0 > 0) ? t0 : t1 (slab_dist) only where two boxes are both met.  Both
+    restatements are checked here over every pair of a set of float32 values that holds the special ones (signed zeros, infinities,
+    NaN, denormals, neighbours of 0 and 1) and random ones of every magnitude."""
+    rng = np.random.default_rng(11)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 1.17549435e-38, -1.17549435e-38, 1.0, -1.0,
+                        np.nextafter(np.float32(1), np.float32(2)), np.nextafter(np.float32(1), np.float32(0)), 3.4028235e38, -3.4028235e38], np.float32)
+    rnd = (rng.normal(size=400) * np.exp(rng.uniform(-80, 80, size=400))).astype(np.float32)
+    vals = np.concatenate([special, rnd, -rnd[:50]])
+    t0, t1 = np.meshgrid(vals, vals, indexing="ij")
+    with np.errstate(invalid="ignore"):
+        r = np.where(t1 >= t0, np.where(t0 > 0, t0, t1), np.float32(-1))
+        met = (t1 >= t0) & (t1 > 0)
+        assert np.array_equal(r > 0, met)
+        dist = np.where(t0 > 0, t0, t1)
+        assert np.array_equal(r[met].view(np.uint32), dist[met].view(np.uint32))  # where a box is met, slab_dist IS the value, bit for bit
