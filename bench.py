@@ -11,8 +11,9 @@ the hot path adding `spp_per_step` samples to every pixel this rank owns; the pe
 sums stay on the GPU between steps, so K steps are K*spp_per_step samples of the same render, not K restarts; the
 defaults (4 steps x 1024 spp) are exactly the 4096-spp render BASELINE.json names.  Multi-GPU: the image's 16x16
 tiles are dealt (tx + ty) % N to the ranks and the samples per step scale with N, so per-GPU work per step is
-constant ("weak"); after the timed steps the framebuffer is collected with ONE gather (RCCL), timed separately as
-gather_ms.  A step may hand its last few unfinished paths to the next step (jade_render_flush, jade_rt.h); the
+constant ("weak"); after the timed steps the framebuffer is collected with ONE gather (RCCL; through host memory over gloo if
+RCCL cannot be brought up on some rank - `exchange` says which), timed separately as gather_ms.  The barriers around the timed
+region and the reduction of the ranks' counts run over gloo: the whole-job figure does not depend on RCCL's bootstrap.  A step may hand its last few unfinished paths to the next step (jade_render_flush, jade_rt.h); the
 warm-up is flushed before the clock starts and the K timed steps are flushed before it stops, so every sample of
 the K steps — `samples` = K * spp * pixels, and all their rays — is computed inside the timed region.
 
@@ -193,13 +194,37 @@ def main():
         local_rank = 0  # every rank shares GPU 0; collectives go through host memory
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    cdev = torch.device("cpu") if rehearsal else dev  # where collective payloads live
+    cdev = torch.device("cpu")  # where the control plane's payloads live (a few doubles per rank)
+    # Two process groups (round 4).  The control plane - the barriers that bracket the timed region and the reduction of the ranks'
+    # counts into the line - runs over gloo: the path has NO data-path collective (tiles are independent), so the whole-job figure
+    # must not depend on whether RCCL's bootstrap likes this host.  The path's one exchange step, the frame gather, goes over RCCL
+    # (device buffers, xGMI) through a group of its own, brought up and exercised HERE, before any clock runs; if that fails on any
+    # rank, every rank agrees (over gloo) to gather through host memory instead, and the line says so (`exchange`).
+    exchange = {"backend": None, "rccl_error": None}
+    rccl_group = None
     if world > 1:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
-            dist.init_process_group("gloo")
+        dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=20))
+        ok = 1.0
+        if rehearsal and not os.environ.get("JADE_BENCH_TRY_RCCL"):
+            ok, exchange["rccl_error"] = 0.0, "rehearsal: the ranks share one GPU"
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            try:
+                rccl_group = dist.new_group(backend="nccl", timeout=datetime.timedelta(minutes=5), device_id=dev)
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe, group=rccl_group)
+                torch.cuda.synchronize()
+                if float(probe.item()) != float(world):
+                    raise RuntimeError("RCCL all_reduce of ones over %d ranks returned %r" % (world, probe.item()))
+            except Exception as e:  # noqa: BLE001 (whatever RCCL's bring-up raises: the bench goes on without it)
+                ok, exchange["rccl_error"] = 0.0, "%s: %s" % (type(e).__name__, str(e)[:300])
+        agreed = torch.tensor([ok], dtype=torch.float64)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)  # (gloo) one rank without RCCL = nobody uses it
+        if agreed.item() < 1.0:
+            rccl_group = None
+            exchange["rccl_error"] = exchange["rccl_error"] or "another rank could not bring RCCL up"
+        exchange["backend"] = "rccl" if rccl_group is not None else "gloo (host memory)"
 
     t0 = time.time()
     dev_build_ms = None
@@ -262,7 +287,10 @@ def main():
     barrier()
     g0 = time.perf_counter()
     scene.resolve_tiles_device(tiles.data_ptr(), torch.cuda.current_stream().cuda_stream)
-    frame = D.gather_framebuffer(tiles.to(cdev), width, height) if world > 1 else None
+    if world > 1:
+        frame = D.gather_framebuffer(tiles, width, height, group=rccl_group) if rccl_group is not None else D.gather_framebuffer(tiles.cpu(), width, height)
+    else:
+        frame = None
     barrier()
     gather_ms = (time.perf_counter() - g0) * 1e3
     if world == 1 and part_world == 1:
@@ -455,6 +483,9 @@ def main():
             "state": state,
             "rays_by_call_site": {k[5:]: float(vals[6 + i].item()) for i, k in enumerate(cls_keys)},
             "gather_ms": gather_ms,
+            # N > 1: what carried the frame gather - "rccl" (device buffers), or "gloo (host memory)" with the reason RCCL was not used;
+            # barriers and the reduction of the ranks' counts always run over gloo (no collective is inside the timed region)
+            "exchange": exchange if world > 1 else None,
             "frame_ok": frame_ok,
             "frame_sha256": frame_sha,   # equal for any number of ranks at equal total samples (tests/test_gpu_bench.py)
             # host waits for the device: per step (the fused first pass, then ONE batch of up to 32 shade / trace passes that

@@ -78,8 +78,9 @@ def test_bench_with_the_occluder_cache():
     assert d["parity_check"]["ok"] is True
 
 
-def _bench_line(args, timeout=900):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout)
+def _bench_line(args, timeout=900, env=None):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout,
+                       env=dict(os.environ, **env) if env else None)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -100,3 +101,16 @@ def test_four_rank_rehearsal_gathers_the_one_rank_frame():
     assert one["frame_ok"] and six["frame_ok"] and one["frame_sha256"] and one["frame_sha256"] == six["frame_sha256"]
     assert one["rays"] == six["rays"] and one["samples"] == six["samples"] == 48 * 1920 * 1080
     assert one["rays_by_call_site"] == six["rays_by_call_site"]
+
+
+def test_a_failed_rccl_bring_up_costs_the_gather_its_backend_not_the_bench_its_line():
+    """bench.py's control plane (barriers, the reduction of the ranks' counts) runs over gloo; RCCL carries only the frame gather and
+    is brought up and exercised before any clock runs.  Here it CANNOT come up - two ranks on the one GPU, which RCCL refuses - and
+    the run must go on: every rank agrees to gather through host memory, the line says why, and frame and rays are those of the one-rank run."""
+    common = ["--config", "C3", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extras"]
+    one = _bench_line(common + ["--spp-per-step", "16"])
+    two = _bench_line(common + ["--gpus", "2", "--dist-backend", "gloo", "--spp-per-step", "8"], env={"JADE_BENCH_TRY_RCCL": "1"})
+    assert one["exchange"] is None
+    ex = two["exchange"]
+    assert ex["backend"].startswith("gloo") and ex["rccl_error"], ex
+    assert two["n_gpus"] == 2 and two["frame_ok"] and two["frame_sha256"] == one["frame_sha256"] and two["rays"] == one["rays"]
