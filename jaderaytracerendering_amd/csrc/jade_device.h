@@ -195,6 +195,11 @@ struct PathState {
   // An ORDERED queue (k_ray_keys + rocPRIM sort; scenes whose tree does not fit the L2) holds queue POSITIONS in the order k_trace is
   // to take them, not slot numbers: position v's ray is record v (v < rayq_cap) or entry v of the index queue, idxq (otherwise).
   const uint32_t* idxq;  // null = the queue k_trace is given IS the index queue, taken in its own order
+  // ... and the kernel that queues a ray writes its sort key beside the entry (keyq[position], position < keyq_cap; null = the queue is
+  // not ordered): it holds the kind of ray, the source triangle and the direction in registers at that moment (ray_sort_key, jade_hip.hip).
+  uint32_t* keyq;
+  uint32_t keyq_cap;
+  uint32_t key_tri_bits;  // bits of the largest triangle index
   uint32_t env_sampling;  // JADE_ENV_*: 1 = environment rays drawn by importance (non-parity mode)
   uint32_t early_exit;  // 0: the reference's walk; 1: early exits; 2: early exits + the occluder cache (JADE_WALK_EARLY_EXIT_CACHED)
 };

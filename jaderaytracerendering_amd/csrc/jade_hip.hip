@@ -93,6 +93,16 @@ static __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t* 
   return x - v;
 }
 
+// The sort key of a queued ray (ordered queues, k_ray_keys below): the kind of ray - shadow ray towards emitter k / environment ray /
+// indirect ray / single-ray stage - then the triangle it leaves (its index in BVH order is a place on the tree's own space-filling
+// curve), then the octant it heads into; left-aligned in 32 bits.
+static __device__ __forceinline__ uint32_t ray_sort_key(uint32_t st, uint32_t k, int n_emit, int32_t skip, float dx, float dy, float dz, uint32_t tri_bits) {
+  uint32_t cls = 7u;  // single-ray stages (mirror, refraction, camera)
+  if (st == ST_DIFFUSE || st == ST_BSSRDF) cls = (int)k < n_emit ? (k < 5u ? k : 4u) : ((int)k == n_emit ? 5u : 6u);
+  const uint32_t tri = skip < 0 ? 0u : ((uint32_t)skip & ((1u << tri_bits) - 1u));
+  const uint32_t oct = (dx < 0.0f ? 1u : 0u) | (dy < 0.0f ? 2u : 0u) | (dz < 0.0f ? 4u : 0u);
+  return (cls << 29) | (((tri << 3) | oct) << (26u - tri_bits));
+}
 static __device__ __forceinline__ unsigned long long wave_sum_u32(uint32_t v) {
   unsigned long long x = v;
 #pragma unroll
@@ -459,7 +469,7 @@ static __device__ __forceinline__ void shade_tail(const PathState& P, int p, uin
     // the record's (camera rays: the eye), direction and limit the slot's, just written by this thread
     jvec3 ro = jv(0, 0, 0);
     int32_t rskip = -1;
-    if (used && P.rayq_cap) {
+    if (used && (P.rayq_cap || P.keyq)) {
       const float4 og = P.orgs[p];
       rskip = __float_as_int(og.w);
       ro = rskip == JADE_SKIP_CAMERA ? jv(P.eye[0], P.eye[1], P.eye[2]) : jv(og.x, og.y, og.z);
@@ -471,6 +481,10 @@ static __device__ __forceinline__ void shade_tail(const PathState& P, int p, uin
       const uint32_t pos = wbase + (uint32_t)__popcll(m & below);
       const uint32_t e = (uint32_t)p * (uint32_t)P.nslots + (uint32_t)k;
       if (q) queue[pos] = e;
+      if (q && P.keyq && pos < P.keyq_cap) {  // ordered queue: the key beside the entry (k_ray_keys read three scattered sectors per ray for it)
+        const float4 dv = sl[0];
+        P.keyq[pos] = ray_sort_key(st, (uint32_t)k, P.nslots - 2, rskip, dv.x, dv.y, dv.z, P.key_tri_bits);
+      }
       if (q && pos < P.rayq_cap) {
         const float4 dv = sl[0];
         jvec3 inv, dn;
@@ -857,11 +871,11 @@ __global__ void k_ray_keys(PathState P, const uint32_t* queue, uint32_t n, uint3
   const float4 og = P.orgs[p];
   const int32_t skip = __float_as_int(og.w);
   const float4 dv = P.slot[(size_t)e];
-  uint32_t cls = 7u;  // single-ray stages (mirror, refraction, camera)
-  if (st == ST_DIFFUSE || st == ST_BSSRDF) cls = (int)k < n_emit ? (k < 5u ? k : 4u) : ((int)k == n_emit ? 5u : 6u);
-  const uint32_t tri = skip < 0 ? 0u : ((uint32_t)skip & ((1u << tri_bits) - 1u));
-  const uint32_t oct = (dv.x < 0.0f ? 1u : 0u) | (dv.y < 0.0f ? 2u : 0u) | (dv.z < 0.0f ? 4u : 0u);
-  keys[i] = (cls << 29) | (((tri << 3) | oct) << (26u - tri_bits));  // left-aligned: kind, triangle, octant
+  keys[i] = ray_sort_key(st, k, n_emit, skip, dv.x, dv.y, dv.z, tri_bits);
+}
+// positions 0 .. n-1: what the sort moves with the keys when the keys came from the queueing kernel (written once per render)
+__global__ void k_iota(uint32_t* v, uint32_t n) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) v[i] = i;
 }
 
 #define JADE_CTL_RING 96 /* QueueCtl records: entry 0 for passes the host follows one by one, all of them for a batch of passes (round 4: 96 - a 1024-spp step of C3 is ~65 passes down to its carry-over point, the flush ~65 more down to k_tail's threshold: one batch, one wait each; the launches behind the stop are empty) */
@@ -1925,6 +1939,7 @@ struct Tunables {
   int records_per_pixel = 0;  // JADE_RECORDS_PER_PIXEL: test hook, results must not depend on it
   int trace_blocks_per_cu = 0;  // JADE_TRACE_BLOCKS_PER_CU: occupancy sweeps
   bool force_rccl = false;    // JADE_FORCE_RCCL=1 (tests): the RCCL path for a single share too
+  bool sort_keys_kernel = false;  // JADE_SORT_KEYS_KERNEL=1: the keys of an ordered queue come from k_ray_keys (a kernel per pass) instead of from the queueing kernel
   int sort_mode = -1;         // JADE_SORT: order the ray queue by (kind, source triangle, octant) before every k_trace launch (host-followed
                               // passes): 1 always, 0 never, unset = when the traversal's records do not fit the L2 (jade_scene.sort_rays)
   uint32_t sort_min = 65536;  // JADE_SORT_MIN: queues shorter than this are traced as they are
@@ -1957,6 +1972,7 @@ struct Tunables {
     force_rccl = getenv("JADE_FORCE_RCCL") != nullptr;
     light_packet = !flag0("JADE_LIGHT_PACKET");
     if (const char* e = getenv("JADE_SORT")) sort_mode = atoi(e) > 0 ? 1 : 0;
+    if (const char* e = getenv("JADE_SORT_KEYS_KERNEL")) sort_keys_kernel = atoi(e) > 0;
     if (const char* e = getenv("JADE_SORT_MIN")) sort_min = (uint32_t)atoi(e);
     if (const char* e = getenv("JADE_PACKET_BUDGET")) packet_budget = atoi(e);
     if (const char* e = getenv("JADE_WIDE")) wide_mode = atoi(e) > 0 ? 1 : 0;
@@ -2663,6 +2679,9 @@ static int setup_state(jade_scene* s, int npx, int rpp, int nslots, int sum_lane
   HIP_TRY(s->b_active[1].alloc(N * 4));
   HIP_TRY(s->b_wavecnt.alloc((size_t)2 * first_pass_blocks * (JADE_TRACE_BLOCK / 64) * 4));
   s->sort_cap = 0;
+  P.keyq = nullptr;
+  P.keyq_cap = 0;
+  P.key_tri_bits = 1;
   if (s->sort_rays) {
     const size_t cap = std::min<size_t>(K * N, (size_t)1 << 28);
     size_t tmp = 0;
@@ -2674,6 +2693,12 @@ static int setup_state(jade_scene* s, int npx, int rpp, int nslots, int sum_lane
     HIP_TRY(s->b_sorttmp.alloc(tmp));
     s->sort_tmp_bytes = tmp;
     s->sort_cap = cap;
+    P.keyq = s->tun.sort_keys_kernel ? nullptr : s->b_sortkey.as<uint32_t>();
+    P.keyq_cap = s->tun.sort_keys_kernel ? 0u : (uint32_t)std::min<size_t>(cap, 0xffffffffu);
+    while (P.key_tri_bits < 23 && ((uint32_t)(s->dev.n_tris - 1) >> P.key_tri_bits)) ++P.key_tri_bits;
+    // the queueing kernel writes the keys itself (PathState.keyq); the positions the sort moves with them are 0 .. cap-1, made once
+    hipLaunchKernelGGL(k_iota, dim3(1024), dim3(256), 0, s->stream, s->b_sortpos.as<uint32_t>(), (uint32_t)std::min<size_t>(cap, 0xffffffffu));
+    HIP_TRY(hipGetLastError());
   }
   if (!s->b_spill.p)
     HIP_TRY(s->b_spill.alloc((size_t)(JADE_BVH_STACK_CAPACITY - JADE_LDS_STACK) * s->trace_blocks * JADE_TRACE_BLOCK * 4));
@@ -3071,10 +3096,11 @@ static int run_passes(jade_scene* s, int64_t from_spp, uint32_t target_spp, bool
     HIP_TRY(hipEventRecord(ta, s->stream));  // (the ordering counts as trace time)
     if (s->sort_rays && host_ctl[0] >= s->tun.sort_min && host_ctl[0] <= s->sort_cap) {
       const uint32_t n = host_ctl[0];
-      uint32_t tri_bits = 1;
-      while (tri_bits < 23 && ((uint32_t)(s->dev.n_tris - 1) >> tri_bits)) ++tri_bits;
-      hipLaunchKernelGGL(k_ray_keys, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->ps, s->b_queue.as<uint32_t>(), n, s->b_sortkey.as<uint32_t>(),
-                         s->b_sortpos.as<uint32_t>(), s->n_emit, tri_bits);
+      // (the keys are in b_sortkey already: the shading kernel wrote each beside its queue entry - PathState.keyq, round 4; until then
+      // k_ray_keys made them here, from three scattered sectors per ray, 2 % of a C5 step.  JADE_SORT_KEYS_KERNEL=1 brings that back.)
+      if (s->tun.sort_keys_kernel)
+        hipLaunchKernelGGL(k_ray_keys, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->ps, s->b_queue.as<uint32_t>(), n, s->b_sortkey.as<uint32_t>(),
+                           s->b_sortpos.as<uint32_t>(), s->n_emit, s->ps.key_tri_bits);
       // The temporary storage was sized once, for (sort_cap entries, bits 0..32).  rocPRIM's need shrinks with the length and with
       // the bit range (fewer digit places, fewer look-back states; a short queue takes its merge-sort path: two buffers of n), and a
       // buffer that is too small is an error return, not a fault (rocprim/detail/temp_storage.hpp: partition) - asked again here,

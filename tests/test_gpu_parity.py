@@ -301,8 +301,9 @@ def test_result_independent_of_ray_ordering(hip, monkeypatch):
         p = B.params_from_config(cfg, spp=spp)
         p.width, p.height = 64, 48
         ref = None
-        for sort in ("0", "1"):
+        for sort, keys_kernel in (("0", "0"), ("1", "0"), ("1", "1")):  # keys from the queueing kernel (the default) / from k_ray_keys
             monkeypatch.setenv("JADE_SORT", sort)
+            monkeypatch.setenv("JADE_SORT_KEYS_KERNEL", keys_kernel)
             monkeypatch.setenv("JADE_SORT_MIN", "64")
             with hip.scene(hs) as sc:
                 rgb, bgr, st = sc.render(p)
