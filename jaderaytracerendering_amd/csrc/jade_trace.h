@@ -65,6 +65,11 @@ enum {
   PL_RESOLVE,      // resolve_pass: barycentric solve of <= 64 candidates, best-hit update
   PL_N_LAPS,
   PC_ITER = PL_N_LAPS, PC_WALK_UNITS, PC_TEST_UNITS, PC_RESOLVES, PC_REFILLS, PC_WAVES, PC_WALK_LANES, PC_TEST_LANES,
+  PC_WALK_WAIT,    // lanes of walk units that hold a ray whose walk has ended (it waits for its leaves' tests)
+  PC_WALK_FREE,    // lanes of walk units that hold no ray
+  PC_TEST_FULL,    // test units with 56 or more lanes
+  PC_TEST_THIN,    // test units with 16 or fewer lanes
+  PC_TEST_THIN_LANES,  // ... and their lanes
   PL_N
 };
 #if JADE_TRACE_PROFILE
@@ -1075,6 +1080,8 @@ struct WaveTrace {
         {  // the walk unit in two laps: the record's fetch (until the data is in registers), then everything else
           PROF_COUNT(pr, PC_WALK_UNITS, 1);
           PROF_COUNT(pr, PC_WALK_LANES, (unsigned long long)__popcll(__ballot(go)));
+          PROF_COUNT(pr, PC_WALK_WAIT, (unsigned long long)__popcll(__ballot(active && !go)));
+          PROF_COUNT(pr, PC_WALK_FREE, (unsigned long long)__popcll(__ballot(!active)));
           if (WIDE && wide) {
             NodeRec4 n4;
             if (go) n4 = node_fetch4(r.cur, S, stk);
@@ -1137,6 +1144,9 @@ struct WaveTrace {
         if (__ballot(go) == 0ull) break;
         PROF_COUNT(pr, PC_TEST_UNITS, 1);
         PROF_COUNT(pr, PC_TEST_LANES, (unsigned long long)__popcll(__ballot(go)));
+        PROF_COUNT(pr, PC_TEST_FULL, __popcll(__ballot(go)) >= 56 ? 1ull : 0ull);
+        PROF_COUNT(pr, PC_TEST_THIN, __popcll(__ballot(go)) <= 16 ? 1ull : 0ull);
+        PROF_COUNT(pr, PC_TEST_THIN_LANES, __popcll(__ballot(go)) <= 16 ? (unsigned long long)__popcll(__ballot(go)) : 0ull);
         // the record first (it depends on the item alone), then the ray the item belongs to
         const uint32_t off = item_leaf & 0x7ffffff0u;
         PairRec rec;

@@ -18,7 +18,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 LAPS = ["top", "writeback", "refill", "pick", "walk_load", "walk_math", "walk_ring", "test_pop", "test_load", "test_ray", "test_math",
         "test_cand", "resolve"]
-COUNTS = ["iterations", "walk_units", "test_units", "resolves", "refills", "waves", "walk_lanes", "test_lanes"]
+COUNTS = ["iterations", "walk_units", "test_units", "resolves", "refills", "waves", "walk_lanes", "test_lanes",
+          "walk_wait_lanes", "walk_free_lanes", "test_units_56_or_more_lanes", "test_units_16_or_fewer_lanes", "lanes_of_thin_test_units"]
 
 
 def main():
@@ -73,6 +74,11 @@ def main():
            "clocks_per_refill": (laps["writeback"] + laps["refill"]) / max(cnt["refills"], 1),
            "clocks_per_iteration_top_and_pick": (laps["top"] + laps["pick"]) / max(cnt["iterations"], 1),
            "lanes_per_walk_unit": cnt["walk_lanes"] / max(cnt["walk_units"], 1), "lanes_per_test_unit": cnt["test_lanes"] / max(cnt["test_units"], 1),
+           "walk_unit_lanes": {"walking": cnt["walk_lanes"] / max(cnt["walk_units"], 1), "waiting_for_tests": cnt["walk_wait_lanes"] / max(cnt["walk_units"], 1),
+                               "without_a_ray": cnt["walk_free_lanes"] / max(cnt["walk_units"], 1)},
+           "test_units": {"share_with_56_or_more_lanes": cnt["test_units_56_or_more_lanes"] / max(cnt["test_units"], 1),
+                          "share_with_16_or_fewer_lanes": cnt["test_units_16_or_fewer_lanes"] / max(cnt["test_units"], 1),
+                          "lanes_per_thin_unit": cnt["lanes_of_thin_test_units"] / max(cnt["test_units_16_or_fewer_lanes"], 1)},
            "wave_units_per_ray": {"walk": cnt["walk_units"] * 64 / max(rays, 1) / 64, "test": cnt["test_units"] / max(rays, 1)},
            "nodes_per_ray": st.nodes_visited / max(st.rays, 1), "tris_per_ray": st.tris_tested / max(st.rays, 1),
            "note": "shader clocks (s_memtime) summed over waves; each lap ends with s_waitcnt vmcnt(0) lgkmcnt(0), so *_load laps are issue -> data in registers; 4 waves share a SIMD: a wave's lap includes the time it waits for the SIMD"}
