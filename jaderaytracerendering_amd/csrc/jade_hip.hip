@@ -81,6 +81,10 @@ struct alignas(8) QueueCtl {
   uint32_t pad[3];
 };
 
+// how many lanes of mask m sit below this one (v_mbcnt_lo + v_mbcnt_hi: two instructions, no per-lane mask kept in registers)
+static __device__ __forceinline__ uint32_t lanes_below(unsigned long long m) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
 static __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t* total) {
   const int lane = threadIdx.x & 63;
   uint32_t x = v;
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(JADE_ARM_BLOCK) void k_arm(PathState P, uint32_t ta
       want = st != ST_IDLE || next_sample(P, (int)p, h.y).sidx < target_spp;
     }
     const unsigned long long m = __ballot(want);
-    off[j] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    off[j] = lanes_below(m);
     if (want) wantm |= 1u << j;
     if (lane == 0) sh_cnt[j * NW + w] = (uint32_t)__popcll(m);
   }
@@ -423,8 +427,7 @@ static __device__ __forceinline__ void shade_tail(const PathState& P, int p, uin
   const uint32_t off = wave_excl_scan((uint32_t)c.n_emit_rays, &total);
   const bool live = c.n_emit_rays > 0;
   const unsigned long long am = __ballot(live), dm = LEAN ? __ballot(defer) : 0ull;
-  const unsigned long long below = (1ull << lane) - 1ull;
-  const uint32_t aoff = (uint32_t)__popcll(am & below), doff = (uint32_t)__popcll(dm & below);
+  const uint32_t aoff = lanes_below(am), doff = lanes_below(dm);
   if (lane == 0) {
     sh_rays[w] = total;
     sh_act[w] = (uint32_t)__popcll(am);
@@ -478,7 +481,7 @@ static __device__ __forceinline__ void shade_tail(const PathState& P, int p, uin
       const float4* sl = P.slot + ((size_t)p * P.nslots + k);
       const bool q = k < used && reinterpret_cast<const int*>(sl)[3] != -2;  // (-2: no ray in this slot; anything else: the queued ray's limit, jade_device.h)
       const unsigned long long m = __ballot(q);
-      const uint32_t pos = wbase + (uint32_t)__popcll(m & below);
+      const uint32_t pos = wbase + lanes_below(m);
       const uint32_t e = (uint32_t)p * (uint32_t)P.nslots + (uint32_t)k;
       if (q) queue[pos] = e;
       if (q && P.keyq && pos < P.keyq_cap) {  // ordered queue: the key beside the entry (k_ray_keys read three scattered sectors per ray for it)
@@ -604,7 +607,6 @@ __global__ __launch_bounds__(JADE_SHADE_BLOCK, JADE_SHADE_BIN_WAVES) void k_shad
   __shared__ uint32_t sh_cnt[JADE_SHADE_NW][BT_N];
   __shared__ uint32_t sh_base[BT_N], sh_n[BT_N];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const unsigned long long below = (1ull << lane) - 1ull;
   const uint32_t t_idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int npix = P.npix;
   const int p = t_idx < n ? (int)list[t_idx] : npix;
@@ -697,7 +699,7 @@ __global__ __launch_bounds__(JADE_SHADE_BLOCK, JADE_SHADE_BIN_WAVES) void k_shad
 #pragma unroll
   for (int T = 1; T < BT_N; ++T) {
     const unsigned long long m = __ballot(type == T);
-    if (type == T) rank = (uint32_t)__popcll(m & below);
+    if (type == T) rank = lanes_below(m);
     if (lane == 0) sh_cnt[w][T] = (uint32_t)__popcll(m);
   }
   __syncthreads();
@@ -1478,7 +1480,7 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_LIGHT_WAVES) void k_light(De
     // ---- hand-over: append to this wave's region
     {
       const unsigned long long dm = __ballot(defer);
-      if (defer) my_region[n_deferred + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull))] = (uint32_t)p;
+      if (defer) my_region[n_deferred + lanes_below(dm)] = (uint32_t)p;
       n_deferred += (uint32_t)__popcll(dm);
     }
   }
@@ -1723,7 +1725,7 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_PACKET_WAVES) void k_light_p
     // ---- hand-over: append to this wave's region
     {
       const unsigned long long dm = __ballot(defer);
-      if (defer) my_region[n_deferred + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull))] = (uint32_t)p;
+      if (defer) my_region[n_deferred + lanes_below(dm)] = (uint32_t)p;
       n_deferred += (uint32_t)__popcll(dm);
     }
   }

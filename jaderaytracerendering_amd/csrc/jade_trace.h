@@ -995,7 +995,6 @@ struct WaveTrace {
   uint32_t q_head, q_count;      // leaves waiting (wave-uniform)
   uint32_t h_head, h_count;      // candidates waiting (wave-uniform)
   uint32_t item_leaf, item_meta; // the leaf this lane is testing (cursor, 0 = none) and its owner | sequence << 6
-  uint32_t below_lo, below_hi;   // the lanes below this one, as two 32-bit masks
   int lane;
   bool wide_kernel;              // the kernel may walk with wide units: ties are marked (resolve_hit)
 
@@ -1006,11 +1005,11 @@ struct WaveTrace {
     q_head = q_count = h_head = h_count = 0;
     item_leaf = item_meta = 0;
     lane = lane_;
-    below_lo = lane_ < 32 ? (1u << lane_) - 1u : 0xffffffffu;
-    below_hi = lane_ < 32 ? 0u : (1u << (lane_ - 32)) - 1u;
   }
-  __device__ __forceinline__ uint32_t rank_in(unsigned long long m) const {  // lanes of m below this one
-    return (uint32_t)__popc((uint32_t)m & below_lo) + (uint32_t)__popc((uint32_t)(m >> 32) & below_hi);
+  // lanes of m below this one: v_mbcnt_lo + v_mbcnt_hi - two instructions and no register (until round 4's last day: two masks kept per
+  // lane, two ands, two popcounts and an add - at the 96-VGPR limit of k_trace)
+  static __device__ __forceinline__ uint32_t rank_in(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
   }
   // the ray of lane `owner`: six registers of that lane (every lane must execute this: ds_bpermute returns 0 for a source
   // lane that is masked off)
