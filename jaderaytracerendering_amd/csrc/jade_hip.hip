@@ -59,6 +59,7 @@
 #define NT_ST(p, v) (*(p) = (v))
 #endif
 #if JADE_TRACE_PROFILE
+__device__ unsigned long long g_packet_prof[PKL_N];  // ... of k_light_packet
 __device__ unsigned long long g_trace_prof[PL_N];  // development profile of k_trace: shader clocks per piece of the loop, summed over waves
 #endif
 typedef float jade_v4f __attribute__((ext_vector_type(4)));
@@ -1536,6 +1537,11 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_PACKET_WAVES) void k_light_p
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const uint32_t stack = lds_addr_of(&lds_stack[w][0]);
   uint32_t n_given_up = 0, n_packets = 0;
+  TraceProf pr;
+#if JADE_TRACE_PROFILE
+  __shared__ __attribute__((aligned(8))) unsigned long long lds_pprof[JADE_TRACE_BLOCK / 64][PKL_N > PL_N ? PKL_N : PL_N];
+  pr.begin(lds_addr_of(reinterpret_cast<const uint32_t*>(&lds_pprof[w][0])), lane);
+#endif
   const int npix = P.npix;
   const size_t sn = (size_t)P.sum_lanes * (size_t)P.npx;
   uint32_t vcnt = 0, tcnt = 0, n_mirror = 0;
@@ -1638,6 +1644,8 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_PACKET_WAVES) void k_light_p
       }
       const bool cam = mine && st == ST_PRIMARY, mir = mine && st == ST_MIRROR;
       const unsigned long long mc = __ballot(cam), mm = __ballot(mir);
+      PROF_DRAIN();
+      PROF_LAP(pr, PKL_ADVANCE);  // (and the fold of the packet before)
       if ((mc | mm) == 0ull) break;  // every lane is out of samples or parked
       // ---- one packet of ONE kind of ray, the kind more lanes hold (a lane with the other kind waits: a wave whose pixels
       // all see the floor alternates camera packets and mirror packets of 64 rays each)
@@ -1649,9 +1657,12 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_PACKET_WAVES) void k_light_p
         PacketBest best;
         uint32_t pv = 0, pt = 0;  // the packet's counts: kept only if it runs to the end
         const bool general = S.general_walk || __ballot(go && exact) != 0ull;
-        whole = general ? packet_trace<true>(S, stack, lane, go, o, d, rp.sk, pv, pt, best, budget)
-                        : packet_trace<false>(S, stack, lane, go, o, d, rp.sk, pv, pt, best, budget);
+        whole = general ? packet_trace<true>(S, stack, lane, go, o, d, rp.sk, pv, pt, best, budget, pr)
+                        : packet_trace<false>(S, stack, lane, go, o, d, rp.sk, pv, pt, best, budget, pr);
         n_packets += 1;
+        PROF_COUNT(pr, PKC_PACKETS, 1);
+        PROF_COUNT(pr, PKC_GIVEN_UP, whole ? 0ull : 1ull);
+        PROF_COUNT(pr, PKC_LANES, (unsigned long long)__popcll(__ballot(go)));
         if (whole) {
           if (go) {
             vcnt += pv + 1u;  // + the root record
@@ -1682,6 +1693,8 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_PACKET_WAVES) void k_light_p
         continue;
       }
       // ---- fold the result in (shade_record's part (a))
+      PROF_DRAIN();
+      PROF_LAP(pr, PKL_POP);  // (what is left of the walk after its last lap)
       if (go) {
         if (st == ST_PRIMARY) {
           if (rp.h < 0) {
@@ -1710,6 +1723,8 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_PACKET_WAVES) void k_light_p
           }
         }
       }
+      PROF_DRAIN();
+      PROF_LAP(pr, PKL_FOLD);
     }
     // ---- store what the next kernel needs
     if (have && st != ST_INVALID && !untouched) {  // (a carried-over record was not touched)
@@ -1728,7 +1743,16 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK, JADE_PACKET_WAVES) void k_light_p
       if (defer) my_region[n_deferred + lanes_below(dm)] = (uint32_t)p;
       n_deferred += (uint32_t)__popcll(dm);
     }
+    PROF_DRAIN();
+    PROF_LAP(pr, PKL_STORE);
   }
+#if JADE_TRACE_PROFILE
+  PROF_DRAIN();
+  if (lane < PKL_N) {
+    const unsigned long long v = pr.get(lane);
+    if (v) atomicAdd(&g_packet_prof[lane], v);
+  }
+#endif
   if (lane == 0) wave_counts[wave_id] = n_deferred;
   // ---- work counters, as k_light
   {
@@ -1777,8 +1801,13 @@ __global__ __launch_bounds__(JADE_TRACE_BLOCK) void k_packet_rays(DevScene S, in
   uint32_t vcnt = have ? 1u : 0u, tcnt = 0;
   PacketBest best;
   bool whole;
-  if (S.general_walk || __ballot(have && exact) != 0ull) whole = packet_trace<true>(S, lds_addr_of(&lds_stack[w][0]), lane, have, o, d, skip[k], vcnt, tcnt, best, 0xffffffffu);
-  else whole = packet_trace<false>(S, lds_addr_of(&lds_stack[w][0]), lane, have, o, d, skip[k], vcnt, tcnt, best, 0xffffffffu);
+  TraceProf pr;
+#if JADE_TRACE_PROFILE
+  __shared__ __attribute__((aligned(8))) unsigned long long lds_pprof[JADE_TRACE_BLOCK / 64][PKL_N > PL_N ? PKL_N : PL_N];
+  pr.begin(lds_addr_of(reinterpret_cast<const uint32_t*>(&lds_pprof[w][0])), lane);
+#endif
+  if (S.general_walk || __ballot(have && exact) != 0ull) whole = packet_trace<true>(S, lds_addr_of(&lds_stack[w][0]), lane, have, o, d, skip[k], vcnt, tcnt, best, 0xffffffffu, pr);
+  else whole = packet_trace<false>(S, lds_addr_of(&lds_stack[w][0]), lane, have, o, d, skip[k], vcnt, tcnt, best, 0xffffffffu, pr);
   if (have && !whole) {  // the packet was given up (no budget here: two leaves tied for some ray's best distance) - k_light_packet hands such rays to the wavefront passes
     hit[i] = -3;
     dist[i] = 0.0f;
@@ -3668,6 +3697,22 @@ int jade_debug_packet_rays(jade_scene* s, int32_t n, const float* origins, const
 
 // Development only (not part of jade_rt.h): the laps of a -DJADE_TRACE_PROFILE=1 build, PL_N values; reset != 0 clears them.
 // A product build reports JADE_ERR_UNSUPPORTED.
+// the same for k_light_packet's laps and counts (jade_trace.h, PKL_*)
+int jade_debug_packet_profile(unsigned long long* out, int n, int reset) {
+#if JADE_TRACE_PROFILE
+  if (!out || n < PKL_N) return fail(JADE_ERR_INVALID, "need room for PKL_N values");
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_packet_prof), sizeof(unsigned long long) * PKL_N));
+  if (reset) {
+    unsigned long long z[PKL_N] = {};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_packet_prof), z, sizeof z));
+  }
+  return PKL_N;
+#else
+  (void)out; (void)n; (void)reset;
+  return -fail(JADE_ERR_UNSUPPORTED, "not a JADE_TRACE_PROFILE build");
+#endif
+}
 int jade_debug_trace_profile(unsigned long long* out, int n, int reset) {
 #if JADE_TRACE_PROFILE
   if (!out || n < PL_N) return fail(JADE_ERR_INVALID, "need room for PL_N values");

@@ -72,6 +72,20 @@ enum {
   PC_TEST_THIN_LANES,  // ... and their lanes
   PL_N
 };
+// ... and of k_light_packet's (the same build; tools/trace_profile.py --packet): laps of a wave's loop over its records, counts of what the packets did
+enum {
+  PKL_ADVANCE = 0,  // every lane without a ray advances until it has one: sample bookkeeping, camera ray, the mirror bounce
+  PKL_PREP,         // packet_trace: 1 / d, normalize(d), the first ballot
+  PKL_NODE,         // node visits: the record's scalar load, two slab tests, ballots, push
+  PKL_LEAF,         // pair records: scalar load, the packed inside test
+  PKL_SOLVE,        // ... and the barycentric solve for the lanes whose origin projects into a triangle
+  PKL_POP,          // the next deferred child off the wave's stack
+  PKL_FOLD,         // the packet's result folded in: the sky (sample_hdr), consume_mirror, a new vertex
+  PKL_STORE,        // header / context stores, the hand-over list
+  PKL_N_LAPS,
+  PKC_PACKETS = PKL_N_LAPS, PKC_GIVEN_UP, PKC_NODES, PKC_PAIRS, PKC_SOLVES, PKC_LANES, PKC_NODE_LANES, PKC_PAIR_LANES, PKC_SOLVE_LANES,
+  PKL_N
+};
 #if JADE_TRACE_PROFILE
 typedef __attribute__((address_space(3))) unsigned long long jade_prof_lds_u64;
 // The laps live in LDS (one row of PL_N 64-bit words per wave, added to by lane 0): as per-lane variables they were 40
@@ -1275,7 +1289,7 @@ static __device__ __forceinline__ void packet_pop(uint32_t stack, uint32_t sp, u
 // lane) cost it 64 walks of one lane each, every record a dependent scalar load.
 template <bool GENERAL>
 static __device__ __forceinline__ bool packet_trace(const DevScene& S, uint32_t stack, int lane, bool active, jvec3 o, jvec3 d, int32_t skip,
-                                                    uint32_t& vcnt, uint32_t& tcnt, PacketBest& best, uint32_t budget) {
+                                                    uint32_t& vcnt, uint32_t& tcnt, PacketBest& best, uint32_t budget, TraceProf& pr) {
   RayOD od;
   const jvec3 inv = jv(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
   const jvec3 dn = jv_normalize(d);
@@ -1293,6 +1307,7 @@ static __device__ __forceinline__ bool packet_trace(const DevScene& S, uint32_t 
   if (lanes == 0ull) return true;
   uint32_t records = 0;
   bool tie = false;
+  PROF_LAP(pr, PKL_PREP);
   for (;;) {
     if (records > budget) return false;
     const bool in = (lanes & me) != 0ull;
@@ -1312,6 +1327,11 @@ static __device__ __forceinline__ bool packet_trace(const DevScene& S, uint32_t 
         bool in_a = false, in_b = false;
         uint32_t idx_a = 0;
         if (in) pair_core(od, skipu, rec, tcnt, in_a, in_b, idx_a);
+        PROF_COUNT(pr, PKC_PAIRS, 1);
+        PROF_COUNT(pr, PKC_PAIR_LANES, (unsigned long long)__popcll(lanes));
+        PROF_COUNT(pr, PKC_SOLVES, __ballot(in_a || in_b) != 0ull ? 1ull : 0ull);
+        PROF_COUNT(pr, PKC_SOLVE_LANES, (unsigned long long)(__popcll(__ballot(in_a)) + __popcll(__ballot(in_b))));
+        PROF_LAP(pr, PKL_LEAF);
         if (in_a || in_b) {  // the origin projects into a triangle: one test in ten; A before B (index order, strict "<")
           const float4* tv = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.tverts) + off);
 #pragma unroll
@@ -1333,6 +1353,7 @@ static __device__ __forceinline__ bool packet_trace(const DevScene& S, uint32_t 
             }
           }
         }
+        PROF_LAP(pr, PKL_SOLVE);  // (everything between a pair's inside test and here: the solves of the lanes with a candidate)
       }
       if (__ballot(tie) != 0ull) return false;  // (twin geometry; the wavefront passes walk these rays in the reference's order)
     } else {
@@ -1355,6 +1376,9 @@ static __device__ __forceinline__ bool packet_trace(const DevScene& S, uint32_t 
         in2 = in && slab_met(s2);
       }
       const unsigned long long m1 = __ballot(in1), m2 = __ballot(in2);
+      PROF_COUNT(pr, PKC_NODES, 1);
+      PROF_COUNT(pr, PKC_NODE_LANES, (unsigned long long)__popcll(lanes));
+      PROF_LAP(pr, PKL_NODE);
       if (m1 != 0ull) {
         if (m2 != 0ull) {
           packet_push(stack, sp, lane, right, m2);
@@ -1374,6 +1398,7 @@ static __device__ __forceinline__ bool packet_trace(const DevScene& S, uint32_t 
     if (sp == 0u) break;
     sp -= 1u;
     packet_pop(stack, sp, cur, lanes);
+    PROF_LAP(pr, PKL_POP);  // (with the push that preceded it, if any)
   }
   return true;
 }

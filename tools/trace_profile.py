@@ -22,6 +22,33 @@ COUNTS = ["iterations", "walk_units", "test_units", "resolves", "refills", "wave
           "walk_wait_lanes", "walk_free_lanes", "test_units_56_or_more_lanes", "test_units_16_or_fewer_lanes", "lanes_of_thin_test_units"]
 
 
+PK_LAPS = ["advance", "prep", "node", "leaf", "solve", "pop", "fold", "store"]
+PK_COUNTS = ["packets", "given_up", "node_visits", "pair_records", "pair_records_with_a_solve", "rays", "node_visit_lanes", "pair_record_lanes", "solve_lanes"]
+
+
+def packet_summary(hip, st):
+    """k_light_packet's laps and counts of the timed steps (jade_debug_packet_profile)."""
+    fn = hip.lib.jade_debug_packet_profile
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    buf = (ctypes.c_ulonglong * 64)()
+    n = fn(buf, 64, 1)
+    assert n == len(PK_LAPS) + len(PK_COUNTS), n
+    v = [int(buf[i]) for i in range(n)]
+    laps, cnt = dict(zip(PK_LAPS, v[:len(PK_LAPS)])), dict(zip(PK_COUNTS, v[len(PK_LAPS):]))
+    total = max(sum(laps.values()), 1)
+    pk = max(cnt["packets"], 1)
+    return {"first_pass_ms": st.light_ms, "clocks_total_all_waves": total, "counts": cnt, "share": {k: x / total for k, x in laps.items()},
+            "per_packet": {"clocks": total / pk, "rays": cnt["rays"] / pk, "node_visits": cnt["node_visits"] / pk, "pair_records": cnt["pair_records"] / pk,
+                           "pair_records_with_a_solve": cnt["pair_records_with_a_solve"] / pk, "given_up": cnt["given_up"] / pk},
+            "clocks_per": {"node_visit": laps["node"] / max(cnt["node_visits"], 1), "pair_record": laps["leaf"] / max(cnt["pair_records"], 1),
+                           "pair_record_with_a_solve": laps["solve"] / max(cnt["pair_records_with_a_solve"], 1),
+                           "packet_advance": laps["advance"] / pk, "packet_prep": laps["prep"] / pk, "packet_fold": laps["fold"] / pk},
+            "lanes_per": {"node_visit": cnt["node_visit_lanes"] / max(cnt["node_visits"], 1), "pair_record": cnt["pair_record_lanes"] / max(cnt["pair_records"], 1),
+                          "solve": cnt["solve_lanes"] / max(cnt["pair_records_with_a_solve"], 1)},
+            "note": "shader clocks (s_memtime) summed over waves, 4 waves share a SIMD; 'advance' holds the sample bookkeeping, the camera ray and the mirror bounce, 'fold' the sky look-up and consume_mirror"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="C3")
@@ -54,11 +81,18 @@ def main():
         sc.flush(w)
         n = fn(buf, 64, 1)
         assert n == len(LAPS) + len(COUNTS), n
+        if hasattr(hip.lib, "jade_debug_packet_profile"):  # (the warm-up's laps: dropped)
+            hip.lib.jade_debug_packet_profile.restype = ctypes.c_int
+            hip.lib.jade_debug_packet_profile.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+            hip.lib.jade_debug_packet_profile((ctypes.c_ulonglong * 64)(), 64, 1)
         st = _abi.Stats()
         for _ in range(a.steps):
             sc.step(a.spp, st)
         sc.flush(st)
         fn(buf, 64, 1)
+        packet = None
+        if hasattr(hip.lib, "jade_debug_packet_profile"):
+            packet = packet_summary(hip, st)
     v = [int(buf[i]) for i in range(n)]
     laps = dict(zip(LAPS, v[:len(LAPS)]))
     cnt = dict(zip(COUNTS, v[len(LAPS):]))
@@ -82,6 +116,7 @@ def main():
            "wave_units_per_ray": {"walk": cnt["walk_units"] * 64 / max(rays, 1) / 64, "test": cnt["test_units"] / max(rays, 1)},
            "nodes_per_ray": st.nodes_visited / max(st.rays, 1), "tris_per_ray": st.tris_tested / max(st.rays, 1),
            "note": "shader clocks (s_memtime) summed over waves; each lap ends with s_waitcnt vmcnt(0) lgkmcnt(0), so *_load laps are issue -> data in registers; 4 waves share a SIMD: a wave's lap includes the time it waits for the SIMD"}
+    out["k_light_packet"] = packet
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     json.dump(out, open(a.out, "w"), indent=1)
     print(json.dumps(out, indent=1))
