@@ -519,7 +519,7 @@ def main():
 def closeup(scene, hip, B, H, _abi, cfg, width, height, spp, walk):
     """The same scene with the camera moved in until the statue fills the frame: every pixel starts a jade path
     (BSSRDF / SSS / mirror branches, ~4 shadow + environment + indirect rays per bounce).  The headline frame is
-    ~5 % statue; this is the rate on the rays it has few of.  One warm-up step, one timed step, both flushed."""
+    ~5 % statue; this is the rate on the rays it has few of.  One warm-up step, two timed steps (the faster one counts), all flushed."""
     import numpy as np
     hs = scene.host_scene
     centre = hs.vertices()[hs.tri_i32()[:, 0] == 0].reshape(-1, 3).mean(0)  # object 0 is the statue (scene_io.cpp add_jade_scene)
@@ -527,17 +527,23 @@ def closeup(scene, hip, B, H, _abi, cfg, width, height, spp, walk):
     eye = centre - 0.22 * forward                                           # C3 looks at it from 0.56 away
     spp = max(1, min(spp, 256))
     p = B.make_params(width, height, spp, [float(x) for x in eye], list(cfg.camera), walk=walk)
+    p.spp = 3 * spp  # (announced = rendered: one warm-up step and two timed ones)
     scene.begin(p)
     w = _abi.Stats()
     scene.step(spp, w)
     scene.flush(w)
-    st = _abi.Stats()
-    t0 = time.perf_counter()
-    scene.step(spp, st)
-    scene.flush(st)
-    dt = time.perf_counter() - t0
+    # two timed steps, the faster one reported (and both times): a side measurement of one second each must not hang on one hiccup of
+    # the box (seen once in round 4: 4.3 s of wall time for 1.03 s of kernels, every other run of the same command 2.70-2.72 Gray/s)
+    runs = []
+    for _ in range(2):
+        st_i = _abi.Stats()
+        t0 = time.perf_counter()
+        scene.step(spp, st_i)
+        scene.flush(st_i)
+        runs.append((time.perf_counter() - t0, st_i))
+    dt, st = min(runs, key=lambda r: r[0])
     rays = float(st.rays_primary + st.rays_secondary)
-    return {"value": rays / dt / 1e6, "unit": "Mray/s", "spp": spp, "rays_per_sample": rays / max(st.samples, 1),
+    return {"value": rays / dt / 1e6, "unit": "Mray/s", "spp": spp, "timed_steps_s": [r[0] for r in runs], "rays_per_sample": rays / max(st.samples, 1),
             "nodes_per_ray": st.nodes_visited / rays, "tris_per_ray": st.tris_tested / rays,
             "k_trace_Mray_per_s": rays / (st.trace_ms * 1e-3) / 1e6 if st.trace_ms else None,
             "trace_share_of_step_time": st.trace_ms / st.kernel_ms if st.kernel_ms else None,
